@@ -1,0 +1,199 @@
+/*
+ * ptk.h -- C ABI of the MI355X path-tracing kernels (libptk.so).
+ *
+ * The reference has no plugin or FFI layer: its render path is a C++ class
+ * API called from src/main.cpp.  This header is the boundary that API is
+ * re-hosted on.  Every entry point names the reference interface it stands
+ * in for.  All arguments are plain pointers, sizes and PODs; `int` results
+ * are 0 on success and negative on failure, with a message available from
+ * ptk_last_error().  Nothing throws or exits across this boundary (the
+ * reference calls exit(1) / assert: src/scene.cpp:107, src/scene.cpp:51).
+ *
+ * A context is bound to one GPU and is not thread-safe; use one context per
+ * device (one process per GPU in multi-GPU runs).  Host input arrays are
+ * copied during the call; device memory belongs to the context until
+ * ptk_destroy().
+ */
+#ifndef PTK_H
+#define PTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_OK 0
+#define PTK_ERR_INVALID (-1) /* bad argument or call order */
+#define PTK_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define PTK_ERR_LIMIT (-3)   /* a documented limit was exceeded */
+
+typedef struct ptk_ctx ptk_ctx;
+
+/* Material::Type, src/material.h:12-18 */
+enum {
+  PTK_DIFFUSE = 1 << 0,
+  PTK_SPECULAR = 1 << 1,
+  PTK_DIELECTRIC = 1 << 2,
+  PTK_MIRROR = 1 << 3,
+  PTK_MICROFACET = 1 << 4
+};
+
+/* Material, src/material.h:11-36 */
+typedef struct {
+  int32_t type;
+  int32_t texture; /* index into ptk_scene_desc.textures, -1 = none (Material::texture) */
+  double albedo[3];
+  double emission[3];
+  double refraction_index;
+  double roughness;
+  double metallic;
+} ptk_material;
+
+/* Image as loaded by Image::load, src/image.cpp:25-31: 8-bit RGB, rows bottom-up */
+typedef struct {
+  const uint8_t* rgb;
+  int32_t width, height;
+} ptk_texture;
+
+/* What Scene holds after load_obj / add_primitive(s) / add_material / set_background_*
+ * (src/scene.h:17-32).  Primitive ids are: triangles 0..n_triangles-1 in array order,
+ * then spheres (src/scene.cpp:56-62 numbering with models before spheres, src/main.cpp:117-145). */
+typedef struct {
+  int32_t n_triangles;
+  const double* tri_pos;        /* n*9: v0 v1 v2              (Triangle, src/geometry.h:38-41) */
+  const double* tri_nrm;        /* n*9: n0 n1 n2 */
+  const double* tri_uv;         /* n*6: t0 t1 t2 */
+  const int32_t* tri_material;  /* n */
+  int32_t n_spheres;
+  const double* sphere_center;  /* n*3                         (Sphere, src/geometry.h:28-32) */
+  const double* sphere_radius;  /* n */
+  const int32_t* sphere_material;
+  int32_t n_materials;
+  const ptk_material* materials;
+  int32_t n_textures;
+  const ptk_texture* textures;
+  int32_t background_texture;   /* Scene::set_background_texture; -1 = none */
+  double background_color[3];   /* Scene::set_background_color; any component < 0 = sky gradient */
+} ptk_scene_desc;
+
+/* Camera state after construction + look_at, src/camera.h:9-26 */
+typedef struct {
+  int32_t width, height;
+  double position[3];
+  double forward[3];
+  double right[3];        /* cross(forward, world_up), src/camera.cpp:80 */
+  double up[3];           /* cross(right, forward),    src/camera.cpp:81 */
+  double fov;             /* radians */
+  double aperture;        /* defocus angle, degrees */
+  double focus_distance;
+} ptk_camera;
+
+/* The compile-time switches of src/config.h:3-8, as run-time values */
+typedef struct {
+  int32_t debug_normal;            /* PT_DEBUG_NORMAL            0 */
+  int32_t russian_roulette;        /* PT_RUSSIAN_ROULETTE        1 */
+  int32_t direct_light_sampling;   /* PT_DIRECT_LIGHT_SAMPLING   1 */
+  int32_t indirect_light_sampling; /* PT_INDIRECT_LIGHT_SAMPLING 1 */
+  int32_t importance_sample;       /* PT_IMPORTANCE_SAMPLE       1 */
+  int32_t check_hemisphere;        /* PT_CHECK_HEMISPHERE        1 */
+} ptk_flags;
+
+/* One Renderer::render call (src/renderer.cpp:27-52) restricted to a share of the frame.
+ * Sample indices are global: this call renders indices sample_first + k*sample_stride,
+ * k = 0..samples-1, of every pixel in rows [row_begin, row_end).  Splitting a frame by
+ * sample index (stride = number of GPUs) or by rows gives the same sample set as one
+ * call on one GPU. */
+typedef struct {
+  int32_t samples;
+  int32_t max_bounce;     /* Renderer::m_max_bounce */
+  uint32_t seed;
+  int32_t sample_first;
+  int32_t sample_stride;  /* >= 1 */
+  int32_t row_begin;      /* 0 */
+  int32_t row_end;        /* <= 0 means height */
+  int32_t collect_stats;  /* 1: also count box / primitive tests (slower kernel variant) */
+} ptk_render_params;
+
+/* Ray, src/ray.h:5-9 */
+typedef struct { double origin[3]; double direction[3]; } ptk_ray;
+
+/* Intersection, src/geometry.h:14-24 (material pointer -> index; hit = has_value) */
+typedef struct {
+  int32_t hit;
+  uint32_t id;
+  float t;
+  float point[3];
+  float normal[3];
+  float uv[2];
+  int32_t material;
+  int32_t inside;
+} ptk_hit;
+
+/* The reference's two global counters (bounce_counter src/renderer.cpp:8,63 and
+ * intersection_test_counter src/geometry.cpp:15,162) plus what the kernels add. */
+typedef struct {
+  uint64_t camera_rays;
+  uint64_t segments;       /* trace_ray bodies = bounce_counter */
+  uint64_t queries;        /* find_intersection calls: segments + shadow rays */
+  uint64_t box_tests;      /* only with collect_stats */
+  uint64_t prim_tests;     /* only with collect_stats = intersection_test_counter */
+  double kernel_ms_last;   /* HIP-event time of the last render / intersect launch */
+  double kernel_ms_total;  /* sum over launches since ptk_reset_stats */
+  uint64_t launches;
+} ptk_stats;
+
+/* Scene layout facts after upload (for roofline accounting and tests) */
+typedef struct {
+  int32_t n_primitives, n_lights, n_nodes, max_depth, max_leaf_size, traversal_kind;
+  uint64_t node_bytes, prim_bytes, shading_bytes, texture_bytes;
+} ptk_scene_info;
+
+/* -- lifetime ---------------------------------------------------------------- */
+int ptk_create(int device, ptk_ctx** out);
+int ptk_destroy(ptk_ctx* ctx);
+/* message of the last failing call on ctx (or of the last failing ptk_create when ctx is NULL) */
+const char* ptk_last_error(const ptk_ctx* ctx);
+
+/* -- scene: stands in for Scene::compute_bvh (src/scene.cpp:80), which in the reference
+ * is the point after which the scene is immutable.  Builds the acceleration structure on
+ * the host and uploads everything. */
+int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
+int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out);
+
+/* -- camera / renderer state: Renderer::Renderer (src/renderer.cpp:19-25) allocates the
+ * W*H accumulation buffer for a camera; ptk_set_camera does that and clears it. */
+int ptk_set_camera(ptk_ctx* ctx, const ptk_camera* camera);
+int ptk_set_flags(ptk_ctx* ctx, const ptk_flags* flags);
+/* Use caller-owned device memory (width*height*4 floats: sum r,g,b + sample count) as the
+ * accumulation buffer, e.g. a tensor that a collective library reduces across GPUs.
+ * NULL returns to the context's own buffer.  The buffer is not cleared. */
+int ptk_bind_accum(ptk_ctx* ctx, float* device_rgbw);
+int ptk_reset_accum(ptk_ctx* ctx);
+
+/* -- Renderer::render (src/renderer.cpp:27-52): launches the path kernel; asynchronous. */
+int ptk_render(ptk_ctx* ctx, const ptk_render_params* params);
+/* -- the buffer Renderer::save_image reads (src/renderer.cpp:186): per-pixel mean radiance,
+ * row 0 = top, W*H*3 floats, host memory.  Blocks until rendering has finished.
+ * total_samples (may be NULL) receives the largest per-pixel sample count. */
+int ptk_read_accum(ptk_ctx* ctx, float* rgb, int32_t* total_samples);
+int ptk_synchronize(ptk_ctx* ctx);
+
+/* -- Scene::find_intersection (src/scene.cpp:19) over a batch of rays.
+ * Host arrays; blocks. */
+int ptk_intersect_batch(ptk_ctx* ctx, const ptk_ray* rays, int32_t n, ptk_hit* hits);
+/* Same with device-resident inputs/outputs: rays as n*6 floats (origin, direction); asynchronous. */
+int ptk_intersect_batch_device(ptk_ctx* ctx, const float* device_rays, int32_t n, ptk_hit* device_hits);
+
+/* -- counters: print_stats (src/geometry.cpp:273-278) */
+int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out); /* blocks */
+int ptk_reset_stats(ptk_ctx* ctx);
+
+/* The HIP stream (hipStream_t) the context launches on, for callers that order their own
+ * work after it. */
+void* ptk_stream(ptk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

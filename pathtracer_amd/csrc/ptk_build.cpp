@@ -1,0 +1,459 @@
+// Host-side scene flattening and BVH construction (see ptk_build.h).
+#include "ptk_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace ptk {
+
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset()
+  {
+    for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::max(); hi[a] = -std::numeric_limits<float>::max(); }
+  }
+  void grow(const Box& b)
+  {
+    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+  }
+  void grow(const float p[3])
+  {
+    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); }
+  }
+  float half_area() const
+  {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.f || dy < 0.f || dz < 0.f) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct BuildNode {
+  Box box;
+  int32_t left = -1, right = -1;  // children (build nodes) or -1
+  int32_t first = 0, count = 0;   // range in the index array (leaves)
+};
+
+// Levels of median splitting needed until every part holds <= kMaxLeafSize primitives.
+int median_levels(int n)
+{
+  int l = 0;
+  while (n > kMaxLeafSize) { n = (n + 1) / 2; l++; }
+  return l;
+}
+
+constexpr int kBins = 16;
+constexpr float kTraversalCost = 1.0f;
+constexpr float kIntersectCost = 1.2f;
+
+struct Builder {
+  const std::vector<Box>& boxes;
+  std::vector<float> centroid;  // 3 per primitive
+  std::vector<int32_t> index;
+  std::vector<BuildNode> nodes;
+  int max_depth = 0, max_leaf = 0;
+
+  explicit Builder(const std::vector<Box>& b) : boxes(b)
+  {
+    size_t n = b.size();
+    centroid.resize(3 * n);
+    index.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      index[i] = (int32_t)i;
+      for (int a = 0; a < 3; a++) centroid[3 * i + a] = 0.5f * (b[i].lo[a] + b[i].hi[a]);
+    }
+    nodes.reserve(2 * n + 1);
+  }
+
+  int32_t build(int first, int count, int depth)
+  {
+    int32_t ni = (int32_t)nodes.size();
+    nodes.emplace_back();
+    Box box, cbox;
+    box.reset(); cbox.reset();
+    for (int i = first; i < first + count; i++) {
+      box.grow(boxes[index[i]]);
+      cbox.grow(&centroid[3 * (size_t)index[i]]);
+    }
+    nodes[ni].box = box;
+    nodes[ni].first = first;
+    nodes[ni].count = count;
+    max_depth = std::max(max_depth, depth);
+
+    // --- choose a split ------------------------------------------------------
+    int best_axis = -1, best_bin = -1;
+    float best_cost = std::numeric_limits<float>::max();
+    float parent_area = box.half_area();
+    if (count > 1 && parent_area > 0.f) {
+      for (int axis = 0; axis < 3; axis++) {
+        float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
+        if (!(ext > 0.f)) continue;
+        Box bin_box[kBins];
+        int bin_count[kBins];
+        for (int b = 0; b < kBins; b++) { bin_box[b].reset(); bin_count[b] = 0; }
+        float scale = (float)kBins / ext;
+        for (int i = first; i < first + count; i++) {
+          int p = index[i];
+          int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * (size_t)p + axis] - lo) * scale)));
+          bin_box[b].grow(boxes[p]);
+          bin_count[b]++;
+        }
+        float right_area[kBins];
+        int right_count[kBins];
+        Box acc;
+        acc.reset();
+        int c = 0;
+        for (int b = kBins - 1; b > 0; b--) {
+          acc.grow(bin_box[b]); c += bin_count[b];
+          right_area[b] = acc.half_area(); right_count[b] = c;
+        }
+        acc.reset();
+        c = 0;
+        for (int b = 0; b < kBins - 1; b++) {
+          acc.grow(bin_box[b]); c += bin_count[b];
+          if (c == 0 || right_count[b + 1] == 0) continue;
+          float cost = kTraversalCost +
+                       kIntersectCost * (acc.half_area() * (float)c + right_area[b + 1] * (float)right_count[b + 1]) /
+                           parent_area;
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+      }
+    }
+    bool must_split = count > kMaxLeafSize;
+    bool want_split = best_axis >= 0 && best_cost < kIntersectCost * (float)count;
+    if (!must_split && (!want_split || depth + 1 > kMaxTreeDepth)) {
+      max_leaf = std::max(max_leaf, count);
+      return ni;
+    }
+
+    int mid = -1;
+    if (best_axis >= 0) {
+      float lo = cbox.lo[best_axis], scale = (float)kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
+      auto* begin = index.data() + first;
+      auto* m = std::partition(begin, begin + count, [&](int32_t p) {
+        int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * (size_t)p + best_axis] - lo) * scale)));
+        return b <= best_bin;
+      });
+      mid = first + (int)(m - begin);
+      int big = std::max(mid - first, first + count - mid);
+      // Depth guard: an unbalanced split is only taken if the larger side can still be finished
+      // by median splits within the depth budget.
+      if (mid == first || mid == first + count || depth + 1 + median_levels(big) > kMaxTreeDepth) mid = -1;
+    }
+    if (mid < 0) {  // object median along the widest centroid axis
+      int axis = 0;
+      float e0 = cbox.hi[0] - cbox.lo[0], e1 = cbox.hi[1] - cbox.lo[1], e2 = cbox.hi[2] - cbox.lo[2];
+      if (e1 > e0 && e1 >= e2) axis = 1;
+      else if (e2 > e0 && e2 > e1) axis = 2;
+      mid = first + (count + 1) / 2;
+      auto* begin = index.data() + first;
+      std::nth_element(begin, begin + (mid - first), begin + count, [&](int32_t a, int32_t b) {
+        float ca = centroid[3 * (size_t)a + axis], cb = centroid[3 * (size_t)b + axis];
+        return ca < cb || (ca == cb && a < b);
+      });
+    }
+    int32_t l = build(first, mid - first, depth + 1);
+    int32_t r = build(mid, first + count - mid, depth + 1);
+    nodes[ni].left = l;
+    nodes[ni].right = r;
+    return ni;
+  }
+};
+
+inline float f_down(double x)
+{
+  float f = (float)x;
+  return ((double)f > x) ? std::nextafter(f, -std::numeric_limits<float>::infinity()) : f;
+}
+inline float f_up(double x)
+{
+  float f = (float)x;
+  return ((double)f < x) ? std::nextafter(f, std::numeric_limits<float>::infinity()) : f;
+}
+
+int32_t leaf_code(int first, int count) { return (int32_t) ~(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
+
+void set_child_box(NodePair& n, int which, const Box& b)
+{
+  if (which == 0) { n.xy0 = f4{b.lo[0], b.hi[0], b.lo[1], b.hi[1]}; n.zz.x = b.lo[2]; n.zz.y = b.hi[2]; }
+  else { n.xy1 = f4{b.lo[0], b.hi[0], b.lo[1], b.hi[1]}; n.zz.z = b.lo[2]; n.zz.w = b.hi[2]; }
+}
+
+}  // namespace
+
+SceneView HostScene::host_view() const
+{
+  SceneView v;
+  std::memset(&v, 0, sizeof v);
+  v.nodes = nodes.data();
+  v.prims = prims.data();
+  v.shade = shade.data();
+  v.materials = materials.data();
+  v.lights = lights.data();
+  v.textures = textures.data();
+  v.texels = texels.data();
+  v.n_prims = n_prims;
+  v.n_lights = (int32_t)lights.size();
+  v.n_nodes = (int32_t)nodes.size();
+  v.n_materials = (int32_t)materials.size();
+  v.background_texture = background_texture;
+  v.background_is_color = background_is_color;
+  for (int i = 0; i < 3; i++) v.background_color[i] = background_color[i];
+  return v;
+}
+
+std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
+{
+  out = HostScene();
+  if (d.n_triangles < 0 || d.n_spheres < 0 || d.n_materials < 0 || d.n_textures < 0) return "negative count";
+  const int64_t n_total = (int64_t)d.n_triangles + (int64_t)d.n_spheres;
+  if (n_total >= (1 << 28)) return "too many primitives (limit 2^28 - 1)";
+  if (d.n_triangles > 0 && (!d.tri_pos || !d.tri_nrm || !d.tri_uv || !d.tri_material)) return "null triangle array";
+  if (d.n_spheres > 0 && (!d.sphere_center || !d.sphere_radius || !d.sphere_material)) return "null sphere array";
+  if (d.n_materials > 0 && !d.materials) return "null material array";
+  if (d.n_textures > 0 && !d.textures) return "null texture array";
+  if (n_total > 0 && d.n_materials == 0) return "primitives need at least one material";
+  if (d.background_texture >= d.n_textures) return "background_texture out of range";
+  const int n = (int)n_total;
+  out.n_prims = n;
+
+  // --- textures ------------------------------------------------------------
+  for (int i = 0; i < d.n_textures; i++) {
+    const ptk_texture& t = d.textures[i];
+    if (t.width <= 0 || t.height <= 0 || !t.rgb) return "invalid texture";
+    TextureRec r;
+    r.offset = out.texels.size();
+    r.width = t.width; r.height = t.height;
+    size_t bytes = (size_t)t.width * (size_t)t.height * 3;
+    out.texels.insert(out.texels.end(), t.rgb, t.rgb + bytes);
+    while (out.texels.size() % 16) out.texels.push_back(0);
+    out.textures.push_back(r);
+  }
+  if (out.textures.empty()) { TextureRec r; r.offset = 0; r.width = r.height = 0; out.textures.push_back(r); }
+  if (out.texels.empty()) out.texels.resize(16, 0);
+
+  // --- materials -------------------------------------------------------------
+  for (int i = 0; i < d.n_materials; i++) {
+    const ptk_material& m = d.materials[i];
+    if (m.texture >= d.n_textures) return "material texture index out of range";
+    MaterialRec r;
+    std::memset(&r, 0, sizeof r);
+    r.type = (uint32_t)m.type;
+    r.texture = m.texture < 0 ? -1 : m.texture;
+    r.ior = (float)m.refraction_index;
+    r.roughness = (float)m.roughness;
+    r.metallic = (float)m.metallic;
+    for (int k = 0; k < 3; k++) { r.albedo[k] = (float)m.albedo[k]; r.emission[k] = (float)m.emission[k]; }
+    if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) r.flags |= kMatLight;
+    bool spec = (m.type & PTK_DIELECTRIC) || (m.type & PTK_MIRROR) ||
+                (((m.type & PTK_SPECULAR) || (m.type & PTK_MICROFACET)) && m.roughness < 1e-5);
+    if (spec) r.flags |= kMatSpecular;
+    out.materials.push_back(r);
+  }
+  if (out.materials.empty()) { MaterialRec r; std::memset(&r, 0, sizeof r); r.type = PTK_DIFFUSE; r.texture = -1; out.materials.push_back(r); }
+
+  // --- primitives: shading records, light list, bounding boxes -----------------------
+  out.shade.resize(std::max(n, 1));
+  std::memset(out.shade.data(), 0, out.shade.size() * sizeof(ShadeRec));
+  std::vector<PrimRec> by_id(std::max(n, 1));
+  std::memset(by_id.data(), 0, by_id.size() * sizeof(PrimRec));
+  std::vector<Box> boxes(n);
+  double max_abs = 1.0;
+  for (int i = 0; i < d.n_triangles; i++) {
+    const double* p = d.tri_pos + 9 * (size_t)i;
+    const double* nr = d.tri_nrm + 9 * (size_t)i;
+    const double* uv = d.tri_uv + 6 * (size_t)i;
+    int mat = d.tri_material[i];
+    if (mat < 0 || mat >= d.n_materials) return "triangle material index out of range";
+    for (int k = 0; k < 9; k++) {
+      if (!std::isfinite(p[k])) return "non-finite triangle vertex";
+      max_abs = std::max(max_abs, std::fabs(p[k]));
+    }
+    ShadeRec& s = out.shade[i];
+    for (int k = 0; k < 3; k++) { s.n0[k] = (float)nr[k]; s.n1[k] = (float)nr[3 + k]; s.n2[k] = (float)nr[6 + k]; }
+    for (int k = 0; k < 2; k++) { s.t0[k] = (float)uv[k]; s.t1[k] = (float)uv[2 + k]; s.t2[k] = (float)uv[4 + k]; }
+    s.material = (uint32_t)mat;
+    PrimRec& r = by_id[i];
+    float v0[3] = {(float)p[0], (float)p[1], (float)p[2]};
+    float e1[3], e2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = (float)(p[3 + k] - (double)v0[k]); e2[k] = (float)(p[6 + k] - (double)v0[k]); }
+    r.a = f4{v0[0], v0[1], v0[2], e1[0]};
+    r.b = f4{e1[1], e1[2], e2[0], e2[1]};
+    r.c = f4{e2[2], as_float((uint32_t)i), as_float((uint32_t)kTriangle), 0.f};
+    Box& b = boxes[i];
+    for (int a = 0; a < 3; a++) {
+      b.lo[a] = f_down(std::min(p[a], std::min(p[3 + a], p[6 + a])));
+      b.hi[a] = f_up(std::max(p[a], std::max(p[3 + a], p[6 + a])));
+    }
+    if (out.materials[mat].flags & kMatLight) {
+      LightRec l;
+      std::memset(&l, 0, sizeof l);
+      l.kind = kTriangle; l.id = (uint32_t)i;
+      double a1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, a2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+      double cx = a1[1] * a2[2] - a2[1] * a1[2], cy = a1[2] * a2[0] - a2[2] * a1[0], cz = a1[0] * a2[1] - a2[0] * a1[1];
+      l.area = (float)(0.5 * std::sqrt(cx * cx + cy * cy + cz * cz));
+      for (int k = 0; k < 3; k++) {
+        l.p0[k] = (float)p[k]; l.p1[k] = (float)p[3 + k]; l.p2[k] = (float)p[6 + k];
+        l.emission[k] = out.materials[mat].emission[k];
+      }
+      out.lights.push_back(l);
+    }
+  }
+  for (int j = 0; j < d.n_spheres; j++) {
+    int i = d.n_triangles + j;
+    const double* c = d.sphere_center + 3 * (size_t)j;
+    double rad = d.sphere_radius[j];
+    int mat = d.sphere_material[j];
+    if (mat < 0 || mat >= d.n_materials) return "sphere material index out of range";
+    if (!std::isfinite(rad) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return "non-finite sphere";
+    ShadeRec& s = out.shade[i];
+    for (int k = 0; k < 3; k++) s.n0[k] = (float)c[k];
+    s.n1[0] = (float)rad;
+    s.material = (uint32_t)mat;
+    PrimRec& r = by_id[i];
+    r.a = f4{(float)c[0], (float)c[1], (float)c[2], (float)rad};
+    r.b = f4{0.f, 0.f, 0.f, 0.f};
+    r.c = f4{0.f, as_float((uint32_t)i), as_float((uint32_t)kSphere), 0.f};
+    Box& b = boxes[i];
+    for (int a = 0; a < 3; a++) {
+      b.lo[a] = f_down(c[a] - std::fabs(rad));
+      b.hi[a] = f_up(c[a] + std::fabs(rad));
+      max_abs = std::max(max_abs, std::max(std::fabs((double)b.lo[a]), std::fabs((double)b.hi[a])));
+    }
+    if (out.materials[mat].flags & kMatLight) {
+      LightRec l;
+      std::memset(&l, 0, sizeof l);
+      l.kind = kSphere; l.id = (uint32_t)i;
+      l.radius = (float)rad;
+      l.area = (float)((4.0 * 3.14159265359 * rad * rad) / 2.0);  // src/geometry.cpp:252
+      for (int k = 0; k < 3; k++) { l.p0[k] = (float)c[k]; l.emission[k] = out.materials[mat].emission[k]; }
+      out.lights.push_back(l);
+    }
+  }
+
+  // Boxes are widened by a few ulps of the largest coordinate: the fp32 slab test and the fp32
+  // triangle test round independently, and a hit on a box face must not be lost to that.
+  const float pad = (float)(max_abs * 8e-7);
+  for (auto& b : boxes)
+    for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
+
+  // --- background --------------------------------------------------------------
+  out.background_texture = d.background_texture < 0 ? -1 : d.background_texture;
+  out.background_is_color = (d.background_color[0] >= 0.0 && d.background_color[1] >= 0.0 && d.background_color[2] >= 0.0);
+  for (int k = 0; k < 3; k++) out.background_color[k] = (float)d.background_color[k];
+
+  // --- BVH -----------------------------------------------------------------------
+  if (n == 0) {
+    NodePair e;
+    std::memset(&e, 0, sizeof e);
+    Box far_box;
+    for (int a = 0; a < 3; a++) far_box.lo[a] = far_box.hi[a] = 1e30f;
+    set_child_box(e, 0, far_box); set_child_box(e, 1, far_box);
+    e.child0 = e.child1 = leaf_code(0, 1);
+    out.nodes.push_back(e);
+    out.prims.assign(1, by_id[0]);
+    return std::string();
+  }
+  Builder bld(boxes);
+  bld.build(0, n, 0);
+  out.max_depth = bld.max_depth;
+  out.max_leaf = bld.max_leaf;
+  if (bld.max_depth > kMaxTreeDepth) return "internal: BVH deeper than the traversal stack allows";
+
+  // Flatten.  Leaves take their primitives in depth-first order; an inner build node becomes
+  // one NodePair carrying both children's boxes.
+  out.prims.reserve(n);
+  struct Item { int32_t build_node; int32_t out_node; };
+  std::vector<int32_t> leaf_first(bld.nodes.size(), -1);
+  // first pass: assign primitive slots to leaves in depth-first order
+  {
+    std::vector<int32_t> stack{0};
+    while (!stack.empty()) {
+      int32_t b = stack.back(); stack.pop_back();
+      const BuildNode& bn = bld.nodes[b];
+      if (bn.left < 0) {
+        leaf_first[b] = (int32_t)out.prims.size();
+        for (int i = bn.first; i < bn.first + bn.count; i++) out.prims.push_back(by_id[bld.index[i]]);
+      } else {
+        stack.push_back(bn.right);
+        stack.push_back(bn.left);
+      }
+    }
+  }
+  auto child_code = [&](int32_t b, std::vector<Item>& todo) -> int32_t {
+    const BuildNode& bn = bld.nodes[b];
+    if (bn.left < 0) return leaf_code(leaf_first[b], bn.count);
+    int32_t idx = (int32_t)out.nodes.size();
+    out.nodes.emplace_back();
+    std::memset(&out.nodes.back(), 0, sizeof(NodePair));
+    todo.push_back(Item{b, idx});
+    return idx;
+  };
+  std::vector<Item> todo;
+  if (bld.nodes[0].left < 0) {  // the whole scene is one leaf
+    NodePair e;
+    std::memset(&e, 0, sizeof e);
+    Box far_box;
+    for (int a = 0; a < 3; a++) far_box.lo[a] = far_box.hi[a] = 1e30f;
+    set_child_box(e, 0, bld.nodes[0].box);
+    set_child_box(e, 1, far_box);
+    e.child0 = e.child1 = leaf_code(0, bld.nodes[0].count);
+    out.nodes.push_back(e);
+    return std::string();
+  }
+  out.nodes.reserve(bld.nodes.size() / 2 + 1);
+  out.nodes.emplace_back();
+  std::memset(&out.nodes.back(), 0, sizeof(NodePair));
+  todo.push_back(Item{0, 0});
+  while (!todo.empty()) {
+    Item it = todo.back(); todo.pop_back();
+    const BuildNode& bn = bld.nodes[it.build_node];
+    // right first so that the left subtree's nodes follow their parent directly in memory
+    std::vector<Item> mine;
+    int32_t c0 = child_code(bn.left, mine);
+    int32_t c1 = child_code(bn.right, mine);
+    NodePair& np = out.nodes[it.out_node];
+    set_child_box(np, 0, bld.nodes[bn.left].box);
+    set_child_box(np, 1, bld.nodes[bn.right].box);
+    np.child0 = c0; np.child1 = c1;
+    for (auto r = mine.rbegin(); r != mine.rend(); ++r) todo.push_back(*r);
+  }
+  return std::string();
+}
+
+CameraView make_camera_view(const ptk_camera& c)
+{
+  CameraView v;
+  std::memset(&v, 0, sizeof v);
+  v.width = c.width; v.height = c.height;
+  for (int k = 0; k < 3; k++) {
+    v.position[k] = (float)c.position[k]; v.forward[k] = (float)c.forward[k];
+    v.right[k] = (float)c.right[k]; v.up[k] = (float)c.up[k];
+  }
+  double aspect = (double)c.width / (double)c.height;
+  double half_height = std::tan(c.fov / 2.0);           // src/camera.cpp:29
+  v.plane_h = (float)(2.0 * half_height);               // src/camera.cpp:33
+  v.plane_w = (float)(2.0 * half_height * aspect);      // src/camera.cpp:30,32
+  v.focus_distance = (float)c.focus_distance;
+  v.defocus_radius = 0.f;
+  if (c.aperture > 0 && c.focus_distance > 0)           // src/camera.cpp:44-50
+    v.defocus_radius = (float)(c.focus_distance * std::tan((c.aperture / 2.0) * 0.017453292519943295));
+  return v;
+}
+
+FlagView make_flag_view(const ptk_flags* f)
+{
+  FlagView v = {0, 1, 1, 1, 1, 1};  // src/config.h:3-8
+  if (f) {
+    v.debug_normal = f->debug_normal; v.russian_roulette = f->russian_roulette;
+    v.direct_light_sampling = f->direct_light_sampling; v.indirect_light_sampling = f->indirect_light_sampling;
+    v.importance_sample = f->importance_sample; v.check_hemisphere = f->check_hemisphere;
+  }
+  return v;
+}
+
+}  // namespace ptk

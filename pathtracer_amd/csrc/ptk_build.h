@@ -1,0 +1,45 @@
+// Host-side scene flattening: turns the C-ABI scene description into the
+// device layout of ptk_layout.h.  Stands where Scene::compute_bvh ->
+// BVH::construct (src/scene.cpp:80, src/bvh.cpp:54-83) stands in the
+// reference, but builds a different tree: binned surface-area-heuristic
+// splits, at most kMaxLeafSize primitives per leaf, depth capped so that the
+// per-lane traversal stack can never overflow.  The closest hit of a ray does
+// not depend on the tree, apart from the reference's own box-test quirks
+// (0.01 entry distance and rejection of zero-thickness boxes,
+// src/bvh.cpp:12, src/aabb.cpp:62).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/ptk.h"
+#include "ptk_layout.h"
+
+namespace ptk {
+
+struct HostScene {
+  std::vector<NodePair> nodes;
+  std::vector<PrimRec> prims;       // BVH leaf order
+  std::vector<ShadeRec> shade;      // by primitive id
+  std::vector<MaterialRec> materials;
+  std::vector<LightRec> lights;     // by primitive id, ascending (Scene::m_lights order, src/scene.cpp:60)
+  std::vector<TextureRec> textures;
+  std::vector<uint8_t> texels;
+  int32_t background_texture = -1;
+  int32_t background_is_color = 0;
+  float background_color[3] = {-1.f, -1.f, -1.f};
+  int32_t n_prims = 0;
+  int32_t max_depth = 0;
+  int32_t max_leaf = 0;
+
+  // Pointers into this object's own vectors (host memory).
+  SceneView host_view() const;
+};
+
+// Returns an empty string on success, otherwise the reason the description was rejected.
+std::string build_host_scene(const ptk_scene_desc& desc, HostScene& out);
+
+CameraView make_camera_view(const ptk_camera& cam);
+FlagView make_flag_view(const ptk_flags* flags);
+
+}  // namespace ptk

@@ -1,0 +1,513 @@
+// HIP kernels for gfx950 and the C ABI of include/ptk.h.
+//
+// One lane per path.  A 256-thread workgroup renders a 16x16 pixel tile; each
+// of its four waves owns an 8x8 sub-tile so that the 64 primary rays of a wave
+// are neighbours.  The traversal stack lives in LDS, strided by lane
+// (stack[level][lane]) so that all 64 lanes of a push or pop touch different
+// banks.  Workgroup ids are remapped so that the workgroups that share an XCD
+// (and its L2) render adjacent tiles.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ptk.h"
+#include "ptk_build.h"
+#include "ptk_shade.h"
+
+namespace ptk {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 16;
+
+struct LdsStack {
+  uint32_t* base;  // this lane's column of the workgroup's LDS array
+  int sp;
+  __device__ __forceinline__ void reset() { sp = 0; }
+  __device__ __forceinline__ bool empty() const { return sp == 0; }
+  __device__ __forceinline__ void push(uint32_t v)
+  {
+    if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // the builder keeps trees shallower than the stack
+  }
+  __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * kBlock]; }
+};
+
+struct RenderArgs {
+  int32_t samples, max_bounce;
+  uint32_t seed;
+  int32_t sample_first, sample_stride;
+  int32_t row_begin, row_end;
+  int32_t tiles_x, n_tiles;
+};
+
+// Workgroups are dealt to the 8 XCDs round-robin, so ids b and b+8 share an L2.  Give each
+// residue class a contiguous run of tiles.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+  int xcd = b & 7, k = b >> 3;
+  int q = n >> 3, r = n & 7;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* out)
+{
+  uint32_t a = wave_sum(c.camera_rays), b = wave_sum(c.segments), q = wave_sum(c.queries);
+  uint32_t x = wave_sum(c.box_tests), p = wave_sum(c.prim_tests);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], (unsigned long long)a);
+    atomicAdd(&out[1], (unsigned long long)b);
+    atomicAdd(&out[2], (unsigned long long)q);
+    atomicAdd(&out[3], (unsigned long long)x);
+    atomicAdd(&out[4], (unsigned long long)p);
+  }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void render_kernel(SceneView sc, CameraView cam, FlagView fl, RenderArgs ra,
+                                                        f4* __restrict__ accum, unsigned long long* counters)
+{
+  __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  LdsStack st;
+  st.base = lds_stack + threadIdx.x;
+  st.sp = 0;
+
+  int tile = xcd_remap((int)blockIdx.x, ra.n_tiles);
+  int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+  int py = ra.row_begin + ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+
+  Counters cnt = {0, 0, 0, 0, 0};
+  if (px < cam.width && py < ra.row_end) {
+    v3 sum = V3(0.f, 0.f, 0.f);
+    for (int s = 0; s < ra.samples; s++) {
+      uint32_t sample = (uint32_t)(ra.sample_first + s * ra.sample_stride);
+      sum += trace_path<LdsStack, STATS>(sc, cam, fl, ra.max_bounce, px, py, sample, ra.seed, st, cnt);
+    }
+    size_t i = (size_t)py * (size_t)cam.width + (size_t)px;
+    f4 a = accum[i];
+    a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)ra.samples;
+    accum[i] = a;
+  }
+  flush_counters(cnt, counters);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
+                                                           ptk_hit* __restrict__ hits, unsigned long long* counters)
+{
+  __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  LdsStack st;
+  st.base = lds_stack + threadIdx.x;
+  st.sp = 0;
+  Counters cnt = {0, 0, 0, 0, 0};
+  int i = (int)(blockIdx.x * kBlock + threadIdx.x);
+  if (i < n) {
+    const float* r = rays + 6 * (size_t)i;
+    v3 o = V3(r[0], r[1], r[2]), d = V3(r[3], r[4], r[5]);
+    Hit hit;
+    cnt.queries++;
+    ptk_hit out;
+    memset(&out, 0, sizeof out);
+    if (closest_hit<LdsStack, STATS>(sc, o, d, kTMax, kNoPrim, st, hit, cnt)) {
+      Surface s;
+      make_surface(sc, o, d, hit, s);
+      out.hit = 1; out.id = hit.id; out.t = hit.t;
+      out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
+      out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
+      out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
+      out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
+    }
+    hits[i] = out;
+  }
+  flush_counters(cnt, counters);
+}
+
+}  // namespace ptk
+
+// ======================================================================== C ABI
+using namespace ptk;
+
+struct ptk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // scene
+  bool have_scene = false;
+  HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
+  SceneView view;
+  void* d_nodes = nullptr; void* d_prims = nullptr; void* d_shade = nullptr; void* d_materials = nullptr;
+  void* d_lights = nullptr; void* d_textures = nullptr; void* d_texels = nullptr;
+  uint64_t texel_bytes = 0;
+  // camera / accumulation
+  bool have_camera = false;
+  CameraView cam;
+  FlagView flags = {0, 1, 1, 1, 1, 1};
+  f4* d_accum_own = nullptr;
+  f4* d_accum = nullptr;  // own or bound
+  size_t accum_pixels = 0;
+  // counters and timing
+  unsigned long long* d_counters = nullptr;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  double ms_last = 0.0, ms_total = 0.0;
+  uint64_t launches = 0;
+};
+
+static std::string g_create_error;
+
+#define PTK_HIP(call)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                              \
+      return PTK_ERR_HIP;                                                                        \
+    }                                                                                            \
+  } while (0)
+
+static int fail(ptk_ctx* ctx, int code, const std::string& msg)
+{
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+static void free_scene(ptk_ctx* ctx)
+{
+  void** ptrs[] = {&ctx->d_nodes, &ctx->d_prims, &ctx->d_shade, &ctx->d_materials, &ctx->d_lights, &ctx->d_textures, &ctx->d_texels};
+  for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+  ctx->have_scene = false;
+}
+
+static int resolve_timing(ptk_ctx* ctx)
+{
+  for (auto& pr : ctx->pending) {
+    PTK_HIP(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    PTK_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+    ctx->ms_last = ms;
+    ctx->ms_total += ms;
+    ctx->pool.push_back(pr);
+  }
+  ctx->pending.clear();
+  return PTK_OK;
+}
+
+static int begin_timed(ptk_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>& ev)
+{
+  if (!ctx->pool.empty()) { ev = ctx->pool.back(); ctx->pool.pop_back(); }
+  else {
+    PTK_HIP(hipEventCreate(&ev.first));
+    PTK_HIP(hipEventCreate(&ev.second));
+  }
+  PTK_HIP(hipEventRecord(ev.first, ctx->stream));
+  return PTK_OK;
+}
+
+static int end_timed(ptk_ctx* ctx, std::pair<hipEvent_t, hipEvent_t>& ev)
+{
+  PTK_HIP(hipEventRecord(ev.second, ctx->stream));
+  ctx->pending.push_back(ev);
+  ctx->launches++;
+  if (ctx->pending.size() > 4096) return resolve_timing(ctx);
+  return PTK_OK;
+}
+
+template <class T>
+static int upload(ptk_ctx* ctx, void** dst, const std::vector<T>& src)
+{
+  size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
+  PTK_HIP(hipMalloc(dst, bytes));
+  if (!src.empty()) PTK_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return PTK_OK;
+}
+
+extern "C" {
+
+int ptk_create(int device, ptk_ctx** out)
+{
+  if (!out) return fail(nullptr, PTK_ERR_INVALID, "ptk_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, PTK_ERR_HIP, std::string("ptk_create: no HIP device available (") + hipGetErrorString(e) + ")");
+  if (device < 0 || device >= n) return fail(nullptr, PTK_ERR_INVALID, "ptk_create: device index out of range");
+  ptk_ctx* ctx = new (std::nothrow) ptk_ctx();
+  if (!ctx) return fail(nullptr, PTK_ERR_INVALID, "ptk_create: out of host memory");
+  ctx->device = device;
+  e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
+  if (e != hipSuccess) {
+    g_create_error = std::string("ptk_create: ") + hipGetErrorString(e);
+    delete ctx;
+    return PTK_ERR_HIP;
+  }
+  *out = ctx;
+  return PTK_OK;
+}
+
+int ptk_destroy(ptk_ctx* ctx)
+{
+  if (!ctx) return PTK_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_scene(ctx);
+  if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PTK_OK;
+}
+
+const char* ptk_last_error(const ptk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!scene) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: scene is NULL");
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  free_scene(ctx);
+  std::string why = build_host_scene(*scene, ctx->host);
+  if (!why.empty()) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: " + why);
+  HostScene& h = ctx->host;
+  int rc;
+  if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
+  if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
+  if ((rc = upload(ctx, &ctx->d_shade, h.shade))) return rc;
+  if ((rc = upload(ctx, &ctx->d_materials, h.materials))) return rc;
+  if ((rc = upload(ctx, &ctx->d_lights, h.lights))) return rc;
+  if ((rc = upload(ctx, &ctx->d_textures, h.textures))) return rc;
+  if ((rc = upload(ctx, &ctx->d_texels, h.texels))) return rc;
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  SceneView v = h.host_view();
+  v.nodes = (const NodePair*)ctx->d_nodes;
+  v.prims = (const PrimRec*)ctx->d_prims;
+  v.shade = (const ShadeRec*)ctx->d_shade;
+  v.materials = (const MaterialRec*)ctx->d_materials;
+  v.lights = (const LightRec*)ctx->d_lights;
+  v.textures = (const TextureRec*)ctx->d_textures;
+  v.texels = (const uint8_t*)ctx->d_texels;
+  ctx->view = v;
+  ctx->texel_bytes = h.texels.size();
+  std::vector<uint8_t>().swap(h.texels);  // the largest host copy is no longer needed
+  ctx->have_scene = true;
+  return PTK_OK;
+}
+
+int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
+{
+  if (!ctx || !out || !ctx->have_scene) return PTK_ERR_INVALID;
+  const HostScene& h = ctx->host;
+  out->n_primitives = h.n_prims;
+  out->n_lights = (int32_t)h.lights.size();
+  out->n_nodes = (int32_t)h.nodes.size();
+  out->max_depth = h.max_depth;
+  out->max_leaf_size = h.max_leaf;
+  out->traversal_kind = 0;
+  out->node_bytes = h.nodes.size() * sizeof(NodePair);
+  out->prim_bytes = h.prims.size() * sizeof(PrimRec);
+  out->shading_bytes = h.shade.size() * sizeof(ShadeRec) + h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec);
+  out->texture_bytes = ctx->texel_bytes;
+  return PTK_OK;
+}
+
+int ptk_set_camera(ptk_ctx* ctx, const ptk_camera* camera)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!camera) return fail(ctx, PTK_ERR_INVALID, "ptk_set_camera: camera is NULL");
+  if (camera->width <= 0 || camera->height <= 0 || (int64_t)camera->width * camera->height > (int64_t)1 << 28)
+    return fail(ctx, PTK_ERR_LIMIT, "ptk_set_camera: image size must be 1 .. 2^28 pixels");
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  size_t pixels = (size_t)camera->width * (size_t)camera->height;
+  if (pixels != ctx->accum_pixels || !ctx->d_accum_own) {
+    bool bound = ctx->d_accum && ctx->d_accum != ctx->d_accum_own;
+    if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
+    ctx->d_accum_own = nullptr;
+    PTK_HIP(hipMalloc((void**)&ctx->d_accum_own, pixels * sizeof(f4)));
+    ctx->accum_pixels = pixels;
+    if (!bound) ctx->d_accum = ctx->d_accum_own;
+    else ctx->d_accum = ctx->d_accum_own;  // a bound buffer of another size is no longer valid
+  }
+  PTK_HIP(hipMemsetAsync(ctx->d_accum_own, 0, pixels * sizeof(f4), ctx->stream));
+  ctx->cam = make_camera_view(*camera);
+  ctx->have_camera = true;
+  return PTK_OK;
+}
+
+int ptk_set_flags(ptk_ctx* ctx, const ptk_flags* flags)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  ctx->flags = make_flag_view(flags);
+  return PTK_OK;
+}
+
+int ptk_bind_accum(ptk_ctx* ctx, float* device_rgbw)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!ctx->have_camera) return fail(ctx, PTK_ERR_INVALID, "ptk_bind_accum: set the camera first");
+  if (device_rgbw && ((uintptr_t)device_rgbw & 15)) return fail(ctx, PTK_ERR_INVALID, "ptk_bind_accum: buffer must be 16-byte aligned");
+  ctx->d_accum = device_rgbw ? (f4*)device_rgbw : ctx->d_accum_own;
+  return PTK_OK;
+}
+
+int ptk_reset_accum(ptk_ctx* ctx)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!ctx->have_camera) return fail(ctx, PTK_ERR_INVALID, "ptk_reset_accum: set the camera first");
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipMemsetAsync(ctx->d_accum, 0, ctx->accum_pixels * sizeof(f4), ctx->stream));
+  return PTK_OK;
+}
+
+int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!p) return fail(ctx, PTK_ERR_INVALID, "ptk_render: params is NULL");
+  if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PTK_ERR_INVALID, "ptk_render: upload a scene and set a camera first");
+  if (p->samples < 0 || p->max_bounce < 0 || p->sample_stride < 1 || p->sample_first < 0)
+    return fail(ctx, PTK_ERR_INVALID, "ptk_render: samples, max_bounce, sample_first must be >= 0 and sample_stride >= 1");
+  if ((int64_t)p->sample_first + (int64_t)p->samples * p->sample_stride > (int64_t)INT32_MAX)
+    return fail(ctx, PTK_ERR_LIMIT, "ptk_render: sample index exceeds 2^31 - 1");
+  RenderArgs ra;
+  ra.samples = p->samples; ra.max_bounce = p->max_bounce; ra.seed = p->seed;
+  ra.sample_first = p->sample_first; ra.sample_stride = p->sample_stride;
+  ra.row_begin = p->row_begin;
+  ra.row_end = p->row_end <= 0 ? ctx->cam.height : p->row_end;
+  if (ra.row_begin < 0 || ra.row_end > ctx->cam.height || ra.row_begin > ra.row_end)
+    return fail(ctx, PTK_ERR_INVALID, "ptk_render: row range outside the image");
+  if (p->samples == 0 || ra.row_begin == ra.row_end) return PTK_OK;
+  ra.tiles_x = (ctx->cam.width + kTile - 1) / kTile;
+  int tiles_y = (ra.row_end - ra.row_begin + kTile - 1) / kTile;
+  ra.n_tiles = ra.tiles_x * tiles_y;
+  PTK_HIP(hipSetDevice(ctx->device));
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  int rc = begin_timed(ctx, ev);
+  if (rc) return rc;
+  dim3 grid((unsigned)ra.n_tiles), block(kBlock);
+  if (p->collect_stats)
+    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum, ctx->d_counters);
+  else
+    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum, ctx->d_counters);
+  PTK_HIP(hipGetLastError());
+  return end_timed(ctx, ev);
+}
+
+int ptk_synchronize(ptk_ctx* ctx)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  return resolve_timing(ctx);
+}
+
+int ptk_read_accum(ptk_ctx* ctx, float* rgb, int32_t* total_samples)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!rgb) return fail(ctx, PTK_ERR_INVALID, "ptk_read_accum: rgb is NULL");
+  if (!ctx->have_camera) return fail(ctx, PTK_ERR_INVALID, "ptk_read_accum: set the camera first");
+  PTK_HIP(hipSetDevice(ctx->device));
+  std::vector<f4> tmp(ctx->accum_pixels);
+  PTK_HIP(hipMemcpyAsync(tmp.data(), ctx->d_accum, tmp.size() * sizeof(f4), hipMemcpyDeviceToHost, ctx->stream));
+  int rc = ptk_synchronize(ctx);
+  if (rc) return rc;
+  float max_w = 0.f;
+  for (size_t i = 0; i < tmp.size(); i++) {
+    float w = tmp[i].w;
+    float inv = w > 0.f ? 1.0f / w : 0.f;
+    rgb[3 * i + 0] = tmp[i].x * inv; rgb[3 * i + 1] = tmp[i].y * inv; rgb[3 * i + 2] = tmp[i].z * inv;
+    if (w > max_w) max_w = w;
+  }
+  if (total_samples) *total_samples = (int32_t)max_w;
+  return PTK_OK;
+}
+
+static int launch_intersect(ptk_ctx* ctx, const float* d_rays, int32_t n, ptk_hit* d_hits, bool stats)
+{
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  int rc = begin_timed(ctx, ev);
+  if (rc) return rc;
+  dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  if (stats) hipLaunchKernelGGL(intersect_kernel<true>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
+  else hipLaunchKernelGGL(intersect_kernel<false>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
+  PTK_HIP(hipGetLastError());
+  return end_timed(ctx, ev);
+}
+
+int ptk_intersect_batch_device(ptk_ctx* ctx, const float* device_rays, int32_t n, ptk_hit* device_hits)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!ctx->have_scene) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch_device: upload a scene first");
+  if (n < 0 || (n > 0 && (!device_rays || !device_hits))) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch_device: bad arguments");
+  if (n == 0) return PTK_OK;
+  PTK_HIP(hipSetDevice(ctx->device));
+  return launch_intersect(ctx, device_rays, n, device_hits, false);
+}
+
+int ptk_intersect_batch(ptk_ctx* ctx, const ptk_ray* rays, int32_t n, ptk_hit* hits)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!ctx->have_scene) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch: upload a scene first");
+  if (n < 0 || (n > 0 && (!rays || !hits))) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch: bad arguments");
+  if (n == 0) return PTK_OK;
+  PTK_HIP(hipSetDevice(ctx->device));
+  std::vector<float> fr(6 * (size_t)n);
+  for (size_t i = 0; i < (size_t)n; i++)
+    for (int k = 0; k < 3; k++) { fr[6 * i + k] = (float)rays[i].origin[k]; fr[6 * i + 3 + k] = (float)rays[i].direction[k]; }
+  float* d_rays = nullptr;
+  ptk_hit* d_hits = nullptr;
+  PTK_HIP(hipMalloc((void**)&d_rays, fr.size() * sizeof(float)));
+  hipError_t e = hipMalloc((void**)&d_hits, (size_t)n * sizeof(ptk_hit));
+  if (e != hipSuccess) { (void)hipFree(d_rays); ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PTK_ERR_HIP; }
+  int rc = PTK_OK;
+  e = hipMemcpyAsync(d_rays, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) rc = launch_intersect(ctx, d_rays, n, d_hits, true);
+  if (e == hipSuccess && rc == PTK_OK) e = hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(ptk_hit), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && rc == PTK_OK) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hits);
+  if (e != hipSuccess) { ctx->err = std::string("ptk_intersect_batch: ") + hipGetErrorString(e); return PTK_ERR_HIP; }
+  if (rc) return rc;
+  return resolve_timing(ctx);
+}
+
+int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
+{
+  if (!ctx || !out) return PTK_ERR_INVALID;
+  int rc = ptk_synchronize(ctx);
+  if (rc) return rc;
+  unsigned long long c[8];
+  PTK_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  out->camera_rays = c[0]; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
+  out->kernel_ms_last = ctx->ms_last; out->kernel_ms_total = ctx->ms_total; out->launches = ctx->launches;
+  return PTK_OK;
+}
+
+int ptk_reset_stats(ptk_ctx* ctx)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  int rc = ptk_synchronize(ctx);
+  if (rc) return rc;
+  PTK_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  ctx->ms_last = ctx->ms_total = 0.0;
+  ctx->launches = 0;
+  return PTK_OK;
+}
+
+void* ptk_stream(ptk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Small float vector helpers shared by the HIP kernels and by host code that
+// prepares their inputs.  Single precision throughout: the kernels trade the
+// reference's double arithmetic (glm::dvec3 everywhere) for fp32, which keeps
+// hit distances within 1e-5 relative of the reference's.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PTK_HD __host__ __device__ __forceinline__
+#else
+#define PTK_HD inline
+#endif
+
+namespace ptk {
+
+struct v3 {
+  float x, y, z;
+};
+
+struct alignas(16) f4 {
+  float x, y, z, w;
+};
+
+PTK_HD v3 V3(float x, float y, float z) { return v3{x, y, z}; }
+PTK_HD v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PTK_HD v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PTK_HD v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+PTK_HD v3 operator*(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+PTK_HD v3 operator*(float s, v3 a) { return v3{a.x * s, a.y * s, a.z * s}; }
+PTK_HD v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+PTK_HD v3& operator+=(v3& a, v3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+PTK_HD v3& operator*=(v3& a, v3 b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; return a; }
+PTK_HD v3& operator*=(v3& a, float s) { a.x *= s; a.y *= s; a.z *= s; return a; }
+PTK_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PTK_HD v3 cross(v3 a, v3 b) { return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+PTK_HD float length(v3 a) { return sqrtf(dot(a, a)); }
+PTK_HD v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+PTK_HD float sqf(float x) { return x * x; }
+
+PTK_HD float as_float(uint32_t u)
+{
+  union { uint32_t u; float f; } c;
+  c.u = u;
+  return c.f;
+}
+PTK_HD uint32_t as_uint(float f)
+{
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  return c.u;
+}
+
+}  // namespace ptk

@@ -1,0 +1,360 @@
+// Per-path work of the reference's renderer, restated for one GPU lane per
+// path: camera ray (src/camera.cpp:19-60), the bounce loop of
+// Renderer::trace_ray with one-light next-event estimation
+// (src/renderer.cpp:57-171, recursion unrolled into throughput form), BSDF
+// sampling / evaluation (src/material.cpp:110-242), texture and environment
+// lookups (src/image.cpp:40-85, src/scene.cpp:21-45).
+//
+// Random numbers: the reference draws from one process-global std::mt19937
+// (src/util.h:72-78); here every path owns a counter-based stream keyed by
+// (seed, pixel, global sample index), so a frame can be split over launches
+// and GPUs by sample index or by rows and still be the same set of paths.
+#pragma once
+
+#include "ptk_traverse.h"
+
+namespace ptk {
+
+constexpr float kPi = 3.14159265359f;  // src/util.h:12
+
+// ---------------------------------------------------------------- random numbers
+struct Rng {
+  uint32_t k0, k1, i;
+};
+
+PTK_HD uint32_t mix32(uint32_t x)
+{
+  x ^= x >> 16; x *= 0x21f0aaadu;
+  x ^= x >> 15; x *= 0x735a2d97u;
+  x ^= x >> 15;
+  return x;
+}
+
+PTK_HD Rng rng_init(uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+  Rng r;
+  r.k0 = mix32(pixel + mix32(seed + 0x9E3779B9u));
+  r.k1 = mix32(sample + 0x85EBCA6Bu) ^ ((r.k0 << 13) | (r.k0 >> 19));
+  r.i = 0;
+  return r;
+}
+
+// uniform in [0,1), 24 bits
+PTK_HD float rnd(Rng& r)
+{
+  uint32_t x = mix32((r.k0 + r.i * 0x9E3779B9u) ^ r.k1);
+  r.i++;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------- small helpers
+PTK_HD v3 ld3(const float* p) { return V3(p[0], p[1], p[2]); }
+
+// util.h:83-89 (y is the polar axis)
+PTK_HD v3 spherical_dir(float cos_theta, float sin_theta, float phi)
+{
+  float s, c;
+  sincosf(phi, &s, &c);
+  return V3(c * sin_theta, cos_theta, s * sin_theta);
+}
+
+// random_unit_vector, util.h:91-96: theta = acos(1 - 2 r1)
+PTK_HD v3 unit_vector_from(float r0, float r1)
+{
+  float ct = 1.0f - 2.0f * r1;
+  float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
+  return spherical_dir(ct, st, 2.0f * kPi * r0);
+}
+
+PTK_HD v3 reflect(v3 I, v3 N) { return I - N * (dot(N, I) * 2.0f); }
+PTK_HD v3 refract(v3 I, v3 N, float eta)
+{
+  float dn = dot(N, I);
+  float k = 1.0f - eta * eta * (1.0f - dn * dn);
+  if (k >= 0.0f) return I * eta - N * (eta * dn + sqrtf(k));
+  return V3(0.0f, 0.0f, 0.0f);
+}
+
+PTK_HD v3 pow3(v3 c, float e) { return V3(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+
+// Orthonormal frame with local +y along the normal (local_to_world, src/util.h:63-70).
+// The reference builds it in float and inverts it numerically; the inverse of an
+// orthonormal matrix is its transpose, which is what to_local uses.
+struct Frame {
+  v3 r, u, f;
+};
+PTK_HD Frame make_frame(v3 up)
+{
+  Frame fr;
+  fr.u = normalize(up);
+  v3 ref = (fabsf(fr.u.z) < 0.9f) ? V3(0.0f, 0.0f, 1.0f) : V3(1.0f, 0.0f, 0.0f);
+  fr.r = normalize(cross(ref, fr.u));
+  fr.f = cross(fr.u, fr.r);
+  return fr;
+}
+PTK_HD v3 to_local(const Frame& fr, v3 w) { return V3(dot(fr.r, w), dot(fr.u, w), dot(fr.f, w)); }
+PTK_HD v3 to_world(const Frame& fr, v3 l) { return fr.r * l.x + fr.u * l.y + fr.f * l.z; }
+
+// ---------------------------------------------------------------- textures
+struct Texel {
+  int r, g, b;
+};
+
+// Image::pixel, src/image.cpp:40-48: out of range gives INVALID_COLOR, which as a u8vec3 is (1,0,1)
+PTK_HD Texel texel(const SceneView& sc, const TextureRec& t, int x, int y)
+{
+  Texel p = {1, 0, 1};
+  if (x < 0 || x >= t.width || y < 0 || y >= t.height) return p;
+  const uint8_t* q = sc.texels + t.offset + ((size_t)y * (size_t)t.width + (size_t)x) * 3;
+  p.r = q[0]; p.g = q[1]; p.b = q[2];
+  return p;
+}
+
+// glm::mix on u8vec3 converts the blended value back to uint8 (truncation) at every lerp, src/image.cpp:78
+PTK_HD Texel mix_u8(Texel a, Texel b, float t)
+{
+  Texel r;
+  r.r = (int)((float)a.r * (1.0f - t) + (float)b.r * t);
+  r.g = (int)((float)a.g * (1.0f - t) + (float)b.g * t);
+  r.b = (int)((float)a.b * (1.0f - t) + (float)b.b * t);
+  return r;
+}
+
+// Image::sample, src/image.cpp:62-85
+PTK_HD v3 sample_texture(const SceneView& sc, int tex, float u, float v)
+{
+  const TextureRec t = sc.textures[tex];
+  float x = u * (float)(t.width - 1);
+  float y = v * (float)(t.height - 1);
+  // int(x) truncates toward zero; NaN and out-of-range coordinates must land outside the image
+  int x0 = (x > -2.0e9f && x < 2.0e9f) ? (int)x : -0x40000000;
+  int y0 = (y > -2.0e9f && y < 2.0e9f) ? (int)y : -0x40000000;
+  float fx = x - (float)x0, fy = y - (float)y0;
+  Texel tl = texel(sc, t, x0, y0), tr = texel(sc, t, x0 + 1, y0);
+  Texel bl = texel(sc, t, x0, y0 + 1), br = texel(sc, t, x0 + 1, y0 + 1);
+  Texel p = mix_u8(mix_u8(tl, tr, fx), mix_u8(bl, br, fx), fy);
+  return V3((float)p.r / 255.0f, (float)p.g / 255.0f, (float)p.b / 255.0f);
+}
+
+// Scene::sample_background, src/scene.cpp:21-45; equirectangular, src/util.h:142-149
+PTK_HD v3 background(const SceneView& sc, v3 dir)
+{
+  if (sc.background_texture >= 0) {
+    float u = atan2f(dir.z, dir.x) * 0.1591f + 0.5f;
+    float v = asinf(dir.y) * 0.3183f + 0.5f;
+    return pow3(sample_texture(sc, sc.background_texture, u, v), 2.2f);
+  }
+  if (sc.background_is_color) return ld3(sc.background_color);
+  float a = 0.5f * (dir.y + 1.0f);
+  return V3(1.0f, 1.0f, 1.0f) * (1.0f - a) + V3(0.5f, 0.7f, 1.0f) * a;
+}
+
+// Intersection::albedo, src/geometry.cpp:18-26
+PTK_HD v3 surface_albedo(const SceneView& sc, const MaterialRec& m, const Surface& s)
+{
+  if (m.texture >= 0) return pow3(sample_texture(sc, m.texture, s.uv[0], s.uv[1]), 2.2f);
+  return ld3(m.albedo);
+}
+
+// ---------------------------------------------------------------- camera
+// Camera::get_ray, src/camera.cpp:19-60.  The image plane spans +-2*tan(fov/2) and the
+// jitter is centred on the integer pixel corner, exactly as there.
+PTK_HD void camera_ray(const CameraView& cam, int x, int y, Rng& g, v3& origin, v3& direction)
+{
+  float jx = rnd(g) - 0.5f, jy = rnd(g) - 0.5f;
+  float uvx = (((float)x + jx) / (float)cam.width) * 2.0f - 1.0f;
+  float uvy = (((float)y + jy) / (float)cam.height) * 2.0f - 1.0f;
+  v3 right = ld3(cam.right), up = ld3(cam.up);
+  v3 dir = normalize(ld3(cam.forward) + right * (cam.plane_w * uvx) - up * (cam.plane_h * uvy));
+  origin = ld3(cam.position);
+  direction = dir;
+  if (cam.defocus_radius > 0.0f) {
+    float dx, dy;
+    for (;;) {  // random_in_unit_disk, src/util.h:98-106
+      dx = 2.0f * rnd(g) - 1.0f;
+      dy = 2.0f * rnd(g) - 1.0f;
+      if (dx * dx + dy * dy < 1.0f) break;
+    }
+    v3 offset = right * (dx * cam.defocus_radius) + up * (dy * cam.defocus_radius);
+    origin = origin + offset;
+    direction = normalize(dir * cam.focus_distance - offset);  // focus_point - origin
+  }
+}
+
+// ---------------------------------------------------------------- BSDF
+// material.cpp:100-106
+PTK_HD float schlick_reflectance(float cosine, float ri)
+{
+  float r0 = (1.0f - ri) / (1.0f + ri);
+  r0 = r0 * r0;
+  float m = 1.0f - cosine;
+  float m2 = m * m;
+  return r0 + (1.0f - r0) * (m2 * m2 * m);
+}
+
+// BxDF::sample, src/material.cpp:110-122.  Draw order: dielectric takes one uniform (the
+// reflect/refract choice), every other type two (direction).
+PTK_HD v3 bsdf_sample(const FlagView& fl, const MaterialRec& m, bool inside, v3 wo, Rng& g)
+{
+  if (m.type == 4u /* DIELECTRIC, :225-240 */) {
+    float r = rnd(g);
+    float ri = inside ? (1.0f / m.ior) : m.ior;
+    v3 N = V3(0.0f, 1.0f, 0.0f);
+    float cos_theta = fminf(wo.y, 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    if ((ri * sin_theta > 1.0f) || (schlick_reflectance(cos_theta, ri) > r)) return reflect(-wo, N);
+    return refract(-wo, N, ri);
+  }
+  float r0 = rnd(g), r1 = rnd(g);
+  if (m.type == 2u /* SPECULAR, :157-162 */)
+    return reflect(-wo, V3(0.0f, 1.0f, 0.0f)) + unit_vector_from(r0, r1) * m.roughness;
+  if (m.type == 16u /* MICROFACET */ && fl.importance_sample) {  // Sample_Beckmann, :57-67
+    float alpha = sqf(m.roughness), alpha2 = sqf(alpha);
+    float tan2 = -alpha2 * logf(1.0f - (r1 / kPi));  // tan^2(theta)
+    float ct = 1.0f / sqrtf(1.0f + tan2);
+    float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
+    v3 H = spherical_dir(ct, st, 2.0f * kPi * r0);
+    return reflect(-wo, H);
+  }
+  // diffuse, :138-144: theta = acos(sqrt(r1))
+  float ct = sqrtf(r1);
+  float st = sqrtf(fmaxf(0.0f, 1.0f - r1));
+  return spherical_dir(ct, st, 2.0f * kPi * r0);
+}
+
+// BxDF::eval, src/material.cpp:124-136
+PTK_HD v3 bsdf_eval(const FlagView& fl, const MaterialRec& m, v3 albedo, v3 V, v3 L)
+{
+  if (m.type == 4u) return V3(1.0f, 1.0f, 1.0f);  // :242
+  if (m.type == 16u) {                            // :175-215
+    if (fl.check_hemisphere && (L.y < 0.0f || V.y < 0.0f)) return V3(0.0f, 0.0f, 0.0f);
+    float alpha = sqf(m.roughness), alpha2 = sqf(alpha);
+    v3 H = normalize(V + L);
+    float NoV = V.y, NoL = L.y, NoH = H.y;
+    float VoH = fabsf(dot(V, H));
+    v3 f0 = V3(0.04f, 0.04f, 0.04f) * (1.0f - m.metallic) + albedo * m.metallic;
+    float p1 = 1.0f - VoH, p2 = p1 * p1;
+    float p5 = p2 * p2 * p1;
+    v3 F = f0 + (V3(1.0f, 1.0f, 1.0f) - f0) * p5;
+    float k = alpha / 2.0f;  // G1_GGX_Schlick, :81-86
+    float G = (fmaxf(NoV, 0.001f) / (NoV * (1.0f - k) + k)) * (fmaxf(NoL, 0.001f) / (NoL * (1.0f - k) + k));
+    float NoH2 = sqf(NoH);
+    float tan2 = (1.0f - NoH2) / NoH2;
+    float e = expf(-tan2 / alpha2);
+    float D = e / (alpha2 * sqf(NoH2));  // D_Beckmann, :44-55
+    float pdf = fl.importance_sample ? e / (alpha2 * NoH2 * NoH * kPi) : NoL / kPi;  // PDF_Beckmann, :69-79
+    v3 specular = F * (G * D / (4.0f * NoV * NoL));
+    return specular * (NoL / pdf);
+  }
+  return albedo;  // diffuse :153, specular :164
+}
+
+PTK_HD float luma(v3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }  // src/renderer.cpp:55
+
+// ---------------------------------------------------------------- next-event estimation
+// Renderer::sample_lights, src/renderer.cpp:130-171.  One uniformly chosen emissive primitive,
+// weight = area * cos(light) / dist^2 * light_count, BSDF evaluated in the LIGHT's frame,
+// no cosine at the shading point and no 1/pi: all as the reference does it.
+template <class Stack, bool STATS>
+PTK_HD v3 sample_lights(const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s, v3 albedo,
+                        v3 incoming, Rng& g, Stack& st, Counters& cnt)
+{
+  v3 zero = V3(0.0f, 0.0f, 0.0f);
+  if (sc.n_lights == 0) return zero;
+  int idx = (int)(rnd(g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
+  if (idx > sc.n_lights - 1) idx = sc.n_lights - 1;
+  const LightRec light = sc.lights[idx];
+  float r1 = rnd(g), r2 = rnd(g);
+  v3 q;
+  if (light.kind == kTriangle) {  // Primitive::sample_point, src/geometry.cpp:228-241
+    float t = sqrtf(r1);
+    float u = 1.0f - t, v = r2 * t, w = 1.0f - u - v;
+    q = ld3(light.p0) * u + ld3(light.p1) * v + ld3(light.p2) * w;
+  } else {
+    v3 c = ld3(light.p0);
+    v3 n = normalize(s.point - c);
+    v3 d = unit_vector_from(r1, r2);
+    if (!(dot(d, n) > 0.0f)) d = -d;
+    q = c + d * light.radius;
+  }
+  v3 to_light = q - s.point;
+  float distance = length(to_light);
+  to_light = to_light * (1.0f / distance);
+  if (s.id == light.id) return zero;  // src/renderer.cpp:146 (the reference traces the ray first; the result is unused)
+  cnt.queries++;
+  // The light is at `distance`; nothing farther can be the closest hit that counts.
+  Hit hit;
+  if (!closest_hit<Stack, STATS>(sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, st, hit, cnt)) return zero;
+  if (hit.id != light.id) return zero;
+  Surface ls;
+  make_surface(sc, s.point, to_light, hit, ls);
+  v3 normal = ls.normal;
+  Frame fr = make_frame(normal);
+  v3 wo = to_local(fr, -incoming);
+  v3 wi = to_local(fr, to_light);
+  float light_cos = fmaxf(dot(normal, -to_light), 0.0f);
+  float weight = light.area * light_cos / (distance * distance);
+  v3 f = bsdf_eval(fl, m, albedo, wo, wi);
+  return ld3(light.emission) * f * (weight * (float)sc.n_lights);
+}
+
+// ---------------------------------------------------------------- the path
+// One camera sample: Camera::get_ray + Renderer::trace_ray(ray, 0).
+template <class Stack, bool STATS>
+PTK_HD v3 trace_path(const SceneView& sc, const CameraView& cam, const FlagView& fl, int max_bounce, int px, int py,
+                     uint32_t sample, uint32_t seed, Stack& st, Counters& cnt)
+{
+  Rng g = rng_init(seed, (uint32_t)(py * cam.width + px), sample);
+  v3 o, d;
+  camera_ray(cam, px, py, g, o, d);
+  cnt.camera_rays++;
+  v3 L = V3(0.0f, 0.0f, 0.0f);
+  v3 beta = V3(1.0f, 1.0f, 1.0f);
+  bool prev_specular = false;
+  uint32_t origin_id = kNoPrim;
+  for (int depth = 0; depth < max_bounce; depth++) {
+    cnt.segments++;
+    cnt.queries++;
+    Hit hit;
+    if (!closest_hit<Stack, STATS>(sc, o, d, kTMax, origin_id, st, hit, cnt)) {
+      L += beta * background(sc, d);
+      break;
+    }
+    Surface s;
+    make_surface(sc, o, d, hit, s);
+    const MaterialRec m = sc.materials[s.material];
+    if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
+      L += beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
+      break;
+    }
+    v3 albedo = surface_albedo(sc, m, s);
+    v3 emission = ld3(m.emission);
+    float rr_weight = 1.0f;
+    if (fl.russian_roulette && depth > 3) {  // src/renderer.cpp:78-90
+      float p = luma(albedo);
+      if (rnd(g) >= p) {
+        L += beta * emission;
+        break;
+      }
+      rr_weight = 1.0f / p;
+    }
+    Frame fr = make_frame(s.normal);
+    v3 wo = to_local(fr, -d);
+    v3 wi = bsdf_sample(fl, m, s.inside, wo, g);
+    bool specular = (m.flags & kMatSpecular) != 0;
+    v3 radiance = V3(0.0f, 0.0f, 0.0f);
+    if (!fl.direct_light_sampling || depth == 0 || specular || prev_specular) radiance += emission;
+    if (fl.direct_light_sampling && !specular)
+      radiance += sample_lights<Stack, STATS>(sc, fl, m, s, albedo, d, g, st, cnt);
+    L += beta * radiance * rr_weight;
+    if (!fl.indirect_light_sampling) break;
+    beta *= bsdf_eval(fl, m, albedo, wo, wi) * rr_weight;
+    o = s.point;
+    d = to_world(fr, wi);  // not renormalised, as in the reference (src/renderer.cpp:121)
+    origin_id = s.id;
+    prev_specular = specular;
+  }
+  return L;
+}
+
+}  // namespace ptk

@@ -1,0 +1,201 @@
+// Closest-hit query: what Scene::find_intersection -> BVH::traverse ->
+// Node::intersect -> Primitive::intersect compute in the reference
+// (src/scene.cpp:19, src/bvh.cpp:10-52, src/geometry.cpp:108-223), restated
+// for one GPU lane per ray:
+//   * iterative, near-child-first traversal of a flattened BVH with the far
+//     child pushed on a short per-lane stack, and pruning against the closest
+//     hit so far (the reference visits both children of every node it enters
+//     and never prunes, src/bvh.cpp:20-22);
+//   * the same acceptance rules: |N.d| < 1e-5 rejects (unnormalised N,
+//     src/geometry.cpp:121), t >= 1e-5 (src/geometry.cpp:131), all three edge
+//     functions >= 0 (src/geometry.cpp:142-154), spheres take the nearer root
+//     inside the open interval (1e-5, 1e9) and otherwise the farther one
+//     (src/geometry.cpp:41-45), the strictly closer hit wins (src/geometry.h:22).
+//
+// fp32 detail: the reference starts secondary rays exactly on the surface
+// they leave and relies on double precision to get t ~ 1e-16 < 1e-5 for the
+// surface itself.  In fp32 that self-distance can exceed 1e-5, so a ray
+// carries the id of the primitive it starts on: a triangle with that id is
+// not tested, a sphere with that id only offers its far root.
+#pragma once
+
+#include "ptk_layout.h"
+
+namespace ptk {
+
+constexpr float kTMin = 1e-5f;  // Interval(0.00001, 1e9), src/geometry.cpp:165
+constexpr float kTMax = 1e9f;
+
+struct Hit {
+  float t;
+  uint32_t id;    // reference primitive id, kNoPrim = miss
+  uint32_t kind;  // PrimKind
+  float u, v;     // triangle: weights of v1 and v2
+};
+
+// Möller-Trumbore form of the reference's plane + three-edge test.
+// det = e1 . (d x e2) = -N.d with N = e1 x e2, so |det| is the reference's |N.d|.
+PTK_HD bool hit_triangle(const PrimRec& p, v3 o, v3 d, float tbest, float& t, float& u, float& v)
+{
+  v3 v0 = V3(p.a.x, p.a.y, p.a.z);
+  v3 e1 = V3(p.a.w, p.b.x, p.b.y);
+  v3 e2 = V3(p.b.z, p.b.w, p.c.x);
+  v3 pvec = cross(d, e2);
+  float det = dot(e1, pvec);
+  if (fabsf(det) < kTMin) return false;
+  float inv = 1.0f / det;
+  v3 tvec = o - v0;
+  float uu = dot(tvec, pvec) * inv;
+  v3 qvec = cross(tvec, e1);
+  float vv = dot(d, qvec) * inv;
+  float tt = dot(e2, qvec) * inv;
+  // edge functions >= 0  <=>  u >= 0, v >= 0, 1-u-v >= 0
+  if (!(uu >= 0.0f && vv >= 0.0f && uu + vv <= 1.0f)) return false;
+  if (!(tt >= kTMin && tt < tbest)) return false;
+  t = tt; u = uu; v = vv;
+  return true;
+}
+
+// Roots of |o + t d - c|^2 = r^2 as (h -+ sqrt(disc)) / a with h = d.(c-o), evaluated from the
+// perpendicular offset l = (c-o) - (h/a) d, which avoids the cancellation of |c-o|^2 - r^2 for
+// far-away origins.  own_surface: the ray starts on this sphere, so one root is 0 by construction
+// and the other is the chord 2h/a (only ahead of the ray when it points inward).
+PTK_HD bool hit_sphere(const PrimRec& p, v3 o, v3 d, float tbest, bool own_surface, float& t)
+{
+  v3 oc = V3(p.a.x, p.a.y, p.a.z) - o;
+  float r = p.a.w;
+  float a = dot(d, d);
+  float h = dot(d, oc);
+  float inv_a = 1.0f / a;
+  float root;
+  if (own_surface) {
+    root = 2.0f * h * inv_a;
+  } else {
+    v3 l = oc - d * (h * inv_a);
+    float disc = a * (r * r - dot(l, l));
+    if (disc < 0.0f) return false;
+    float sqrtd = sqrtf(disc);
+    root = (h - sqrtd) * inv_a;
+    if (!(kTMin < root && root < kTMax)) root = (h + sqrtd) * inv_a;
+  }
+  if (!(kTMin < root && root < kTMax)) return false;
+  if (!(root < tbest)) return false;
+  t = root;
+  return true;
+}
+
+// Slab test of one child box against [0, tbest]; returns entry distance in tn.
+// fminf/fmaxf drop NaNs from 0 * inf, so an axis-parallel ray lying exactly in a box face
+// is kept on that axis (the reference's comparisons do the same, src/aabb.cpp:54-62).
+PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float hiz, v3 o, v3 inv, float tbest,
+                    float& tn)
+{
+  float tx0 = (lox - o.x) * inv.x, tx1 = (hix - o.x) * inv.x;
+  float ty0 = (loy - o.y) * inv.y, ty1 = (hiy - o.y) * inv.y;
+  float tz0 = (loz - o.z) * inv.z, tz1 = (hiz - o.z) * inv.z;
+  float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+  float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+  tn = tnear;
+  return tnear <= tfar * 1.0000005f;  // a few ulps of slack: boxes of axis-aligned walls have zero thickness
+}
+
+// Stack: push(uint32_t), pop() -> uint32_t, empty(), reset().
+// skip_id: primitive the ray starts on (kNoPrim for none).
+template <class Stack, bool STATS>
+PTK_HD bool closest_hit(const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id, Stack& st, Hit& hit,
+                        Counters& cnt)
+{
+  hit.t = tmax;
+  hit.id = kNoPrim;
+  hit.kind = kTriangle;
+  hit.u = hit.v = 0.0f;
+  if (sc.n_prims <= 0) return false;
+  v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  st.reset();
+  int32_t node = 0;
+  for (;;) {
+    if (node >= 0) {
+      const NodePair n = sc.nodes[node];
+      float tn0, tn1;
+      bool h0 = hit_box(n.xy0.x, n.xy0.y, n.xy0.z, n.xy0.w, n.zz.x, n.zz.y, o, inv, hit.t, tn0);
+      bool h1 = hit_box(n.xy1.x, n.xy1.y, n.xy1.z, n.xy1.w, n.zz.z, n.zz.w, o, inv, hit.t, tn1);
+      if (STATS) cnt.box_tests += 2;
+      if (h0 && h1) {
+        bool swap = tn1 < tn0;
+        st.push((uint32_t)(swap ? n.child0 : n.child1));
+        node = swap ? n.child1 : n.child0;
+        continue;
+      }
+      if (h0) { node = n.child0; continue; }
+      if (h1) { node = n.child1; continue; }
+    } else {
+      uint32_t leaf = ~(uint32_t)node;
+      uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+      for (uint32_t i = 0; i < count; i++) {
+        const PrimRec p = sc.prims[first + i];
+        uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
+        if (STATS) cnt.prim_tests++;
+        if (kind == kTriangle) {
+          if (id == skip_id) continue;
+          float t, u, v;
+          if (hit_triangle(p, o, d, hit.t, t, u, v)) { hit.t = t; hit.id = id; hit.kind = kind; hit.u = u; hit.v = v; }
+        } else {
+          float t;
+          if (hit_sphere(p, o, d, hit.t, id == skip_id, t)) { hit.t = t; hit.id = id; hit.kind = kind; hit.u = hit.v = 0.0f; }
+        }
+      }
+    }
+    if (st.empty()) break;
+    node = (int32_t)st.pop();
+  }
+  return hit.id != kNoPrim;
+}
+
+// The Intersection record of the reference (src/geometry.h:14-24) for a closest hit,
+// filled the way Primitive::intersect does (src/geometry.cpp:166-219).
+struct Surface {
+  v3 point, normal;   // normal: interpolated vertex normals, NOT normalised (src/geometry.cpp:100-105)
+  float uv[2];
+  uint32_t id, material;
+  bool inside;
+};
+
+PTK_HD float atan2_ref(float y, float x) { return atan2f(y, x); }
+
+PTK_HD void make_surface(const SceneView& sc, v3 o, v3 d, const Hit& hit, Surface& s)
+{
+  const ShadeRec sh = sc.shade[hit.id];
+  const MaterialRec& m = sc.materials[sh.material];
+  s.id = hit.id;
+  s.material = sh.material;
+  s.point = o + d * hit.t;  // Ray::point_at, src/ray.h:8
+  s.uv[0] = s.uv[1] = 0.0f;
+  v3 normal;
+  bool keep_normal = false;
+  if (hit.kind == kTriangle) {
+    float w0 = 1.0f - hit.u - hit.v;
+    normal = V3(sh.n0[0], sh.n0[1], sh.n0[2]) * w0 + V3(sh.n1[0], sh.n1[1], sh.n1[2]) * hit.u +
+             V3(sh.n2[0], sh.n2[1], sh.n2[2]) * hit.v;
+    keep_normal = (m.flags & kMatLight) != 0;  // lights keep their stored normal, src/geometry.cpp:199-201
+    if (m.texture >= 0) {  // Triangle::texcoord, src/geometry.cpp:86-91
+      s.uv[0] = w0 * sh.t0[0] + hit.u * sh.t1[0] + hit.v * sh.t2[0];
+      s.uv[1] = w0 * sh.t0[1] + hit.u * sh.t1[1] + hit.v * sh.t2[1];
+    }
+  } else {
+    v3 c = V3(sh.n0[0], sh.n0[1], sh.n0[2]);
+    normal = (s.point - c) * (1.0f / sh.n1[0]);
+    if (m.texture >= 0) {  // Sphere::texcoord, src/geometry.cpp:56-64
+      v3 q = normalize(s.point - c);
+      const float pi = 3.14159265359f;
+      float theta = acosf(-q.y);
+      float phi = atan2_ref(-q.z, q.x) + pi;
+      s.uv[0] = phi / (2.0f * pi);
+      s.uv[1] = theta / pi;
+    }
+  }
+  if (keep_normal) { s.normal = normal; s.inside = true; }
+  else if (dot(d, normal) > 0.0f) { s.normal = -normal; s.inside = false; }
+  else { s.normal = normal; s.inside = true; }
+}
+
+}  // namespace ptk

@@ -1,0 +1,123 @@
+// TEST HARNESS ONLY -- never part of libptk.so and never loaded by the package.
+//
+// Compiles the kernels' per-lane device functions (ptk_traverse.h, ptk_shade.h) and the host-side
+// scene flattening (ptk_build.cpp) for the CPU, and runs them lane by lane.  This lets the CPU-only
+// test suite check the fp32 kernel logic against the oracle in a container without a GPU; the GPU
+// tests then check the real kernels through the C ABI.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptk.h"
+#include "../../pathtracer_amd/csrc/ptk_build.h"
+#include "../../pathtracer_amd/csrc/ptk_shade.h"
+
+using namespace ptk;
+
+namespace {
+struct HostStack {
+  uint32_t data[kStackDepth];
+  int sp = 0;
+  int high_water = 0;
+  void reset() { sp = 0; }
+  bool empty() const { return sp == 0; }
+  void push(uint32_t v)
+  {
+    if (sp < kStackDepth) data[sp++] = v;
+    if (sp > high_water) high_water = sp;
+  }
+  uint32_t pop() { return data[--sp]; }
+};
+
+struct Check {
+  HostScene host;
+  std::string err;
+};
+}  // namespace
+
+extern "C" {
+
+void* hc_create(const ptk_scene_desc* d)
+{
+  Check* c = new Check();
+  c->err = build_host_scene(*d, c->host);
+  return c;
+}
+const char* hc_error(void* h) { return ((Check*)h)->err.c_str(); }
+void hc_destroy(void* h) { delete (Check*)h; }
+
+void hc_info(void* h, int32_t* out /* n_nodes, max_depth, max_leaf, n_lights, n_prims */)
+{
+  Check* c = (Check*)h;
+  out[0] = (int32_t)c->host.nodes.size(); out[1] = c->host.max_depth; out[2] = c->host.max_leaf;
+  out[3] = (int32_t)c->host.lights.size(); out[4] = c->host.n_prims;
+}
+
+// returns the deepest stack use seen
+int hc_intersect(void* h, const ptk_ray* rays, int n, ptk_hit* hits, uint64_t* counters /* box, prim */)
+{
+  Check* c = (Check*)h;
+  SceneView sc = c->host.host_view();
+  int high = 0;
+  Counters cnt = {0, 0, 0, 0, 0};
+  uint64_t box = 0, prim = 0;
+  for (int i = 0; i < n; i++) {
+    HostStack st;
+    v3 o = V3((float)rays[i].origin[0], (float)rays[i].origin[1], (float)rays[i].origin[2]);
+    v3 d = V3((float)rays[i].direction[0], (float)rays[i].direction[1], (float)rays[i].direction[2]);
+    Hit hit;
+    ptk_hit out;
+    std::memset(&out, 0, sizeof out);
+    cnt.box_tests = cnt.prim_tests = 0;
+    if (closest_hit<HostStack, true>(sc, o, d, kTMax, kNoPrim, st, hit, cnt)) {
+      Surface s;
+      make_surface(sc, o, d, hit, s);
+      out.hit = 1; out.id = hit.id; out.t = hit.t;
+      out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
+      out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
+      out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
+      out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
+    }
+    box += cnt.box_tests; prim += cnt.prim_tests;
+    hits[i] = out;
+    if (st.high_water > high) high = st.high_water;
+  }
+  if (counters) { counters[0] = box; counters[1] = prim; }
+  return high;
+}
+
+// accum: W*H*4 floats (sum r,g,b, count), same meaning as the device accumulation buffer
+void hc_render(void* h, const ptk_camera* camera, const ptk_flags* flags, const ptk_render_params* p, float* accum,
+               uint64_t* counters /* camera, segments, queries, box, prim */)
+{
+  Check* c = (Check*)h;
+  SceneView sc = c->host.host_view();
+  CameraView cam = make_camera_view(*camera);
+  FlagView fl = make_flag_view(flags);
+  int row_end = p->row_end <= 0 ? cam.height : p->row_end;
+  uint64_t tot[5] = {0, 0, 0, 0, 0};
+#pragma omp parallel
+  {
+    uint64_t loc[5] = {0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 1)
+    for (int y = p->row_begin; y < row_end; y++) {
+      for (int x = 0; x < cam.width; x++) {
+        HostStack st;
+        Counters cnt = {0, 0, 0, 0, 0};
+        v3 sum = V3(0.f, 0.f, 0.f);
+        for (int s = 0; s < p->samples; s++) {
+          uint32_t sample = (uint32_t)(p->sample_first + s * p->sample_stride);
+          sum += trace_path<HostStack, true>(sc, cam, fl, p->max_bounce, x, y, sample, p->seed, st, cnt);
+        }
+        float* a = accum + 4 * ((size_t)y * cam.width + x);
+        a[0] += sum.x; a[1] += sum.y; a[2] += sum.z; a[3] += (float)p->samples;
+        loc[0] += cnt.camera_rays; loc[1] += cnt.segments; loc[2] += cnt.queries; loc[3] += cnt.box_tests; loc[4] += cnt.prim_tests;
+      }
+    }
+#pragma omp critical
+    for (int k = 0; k < 5; k++) tot[k] += loc[k];
+  }
+  if (counters) for (int k = 0; k < 5; k++) counters[k] = tot[k];
+}
+
+}  // extern "C"

@@ -239,12 +239,16 @@ PTK_HD v3 bsdf_eval(const FlagView& fl, const MaterialRec& m, v3 albedo, v3 V, v
     float k = alpha / 2.0f;  // G1_GGX_Schlick, :81-86
     float G = (fmaxf(NoV, 0.001f) / (NoV * (1.0f - k) + k)) * (fmaxf(NoL, 0.001f) / (NoL * (1.0f - k) + k));
     float NoH2 = sqf(NoH);
-    float tan2 = (1.0f - NoH2) / NoH2;
-    float e = expf(-tan2 / alpha2);
-    float D = e / (alpha2 * sqf(NoH2));  // D_Beckmann, :44-55
-    float pdf = fl.importance_sample ? e / (alpha2 * NoH2 * NoH * kPi) : NoL / kPi;  // PDF_Beckmann, :69-79
-    v3 specular = F * (G * D / (4.0f * NoV * NoL));
-    return specular * (NoL / pdf);
+    float x = ((1.0f - NoH2) / NoH2) / alpha2;  // tan^2(theta_h) / alpha^2
+    // D_Beckmann (:44-55) = exp(-x) / (alpha2 NoH^4); PDF_Beckmann (:69-79) = exp(-x) / (alpha2 NoH^3 pi).
+    // With importance sampling the reference divides one by the other; exp(-x) cancels to pi / NoH.  In
+    // fp32 exp(-x) underflows long before it does in the reference's doubles (x > 87 vs x > 745), so the
+    // quotient is formed analytically and 0/0 = NaN is kept only where doubles would underflow too.
+    float d_over_pdf;
+    if (fl.importance_sample) d_over_pdf = (x > 745.0f) ? (0.0f / 0.0f) : kPi / NoH;
+    else d_over_pdf = (expf(-x) / (alpha2 * sqf(NoH2))) / (NoL / kPi);
+    v3 specular = F * (G / (4.0f * NoV * NoL));
+    return specular * (NoL * d_over_pdf);
   }
   return albedo;  // diffuse :153, specular :164
 }

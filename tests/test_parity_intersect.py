@@ -1,0 +1,133 @@
+"""First correctness check: closest-hit primitive ids on fixed, seeded ray batches match the oracle exactly
+(except for the stated, counted classes of rounding ties) and hit distances agree within 1e-5 relative.
+
+Runs against the kernels' device functions compiled for the CPU ("hostcheck", no GPU needed) and against the
+HIP kernels through the C ABI ("gpu")."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests import parity, raygen
+from tests.backends import BACKENDS, make_backend, scene
+
+
+def _oracle(sd):
+    return orc.OracleScene(sd)
+
+
+def _f32_rays(rays):
+    """Round ray data through float32 so that the oracle and the fp32 kernels see identical inputs."""
+    return np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("scene_name,n", [("cornell", 60000), ("mesh", 30000), ("glass", 30000)])
+def test_random_rays_ids_exact(backend, scene_name, n, request):
+    sd = scene(scene_name)
+    o = _oracle(sd)
+    b = make_backend(backend, sd, request)
+    rays = _f32_rays(np.concatenate([raygen.interior_rays(n, 42), raygen.camera_like_rays(n // 2, 43)]))
+    ref, _ = o.intersect(rays)
+    got, _ = b.intersect(rays)
+    c = parity.classify_hits(sd, rays, ref, got)
+    print(scene_name, c)
+    assert c["unexplained"] == 0, c
+    excused = c["tie"] + c["near"] + c["ref_miss"] + c["graze"] + c["cond"]
+    assert excused <= max(3, 1e-4 * c["n"]), c  # total excused <= 1e-4 of rays on random batches
+    assert c["max_rel_t"] <= 1e-5, c
+    rec = parity.check_hit_records(ref, got)
+    print(rec)
+    assert rec["point"] < 1e-5 and rec["uv"] < 1e-4 and rec["material_mismatch"] == 0
+    assert rec["normal"] < 1e-5
+    assert rec["inside_mismatch"] <= 1e-4 * rec["n"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("scene_name", ["cornell", "mesh"])
+def test_secondary_rays_start_on_surfaces(backend, scene_name, request):
+    """Rays whose origin lies exactly on a surface (no offset, like the reference's bounce and shadow rays).
+    Differences here are limited to hits within rounding distance of the origin ("near")."""
+    sd = scene(scene_name)
+    o = _oracle(sd)
+    b = make_backend(backend, sd, request)
+    first, _ = o.intersect(_f32_rays(raygen.interior_rays(20000, 7)))
+    rays = _f32_rays(raygen.secondary_rays(first, 8))
+    ref, _ = o.intersect(rays)
+    got, _ = b.intersect(rays)
+    c = parity.classify_hits(sd, rays, ref, got)
+    print(scene_name, c)
+    assert c["unexplained"] == 0, c
+    assert c["tie"] + c["ref_miss"] + c["graze"] <= max(3, 2e-4 * c["n"]), c
+    assert c["cond"] <= 1e-3 * c["n"], c
+    assert c["near"] <= 2e-2 * c["n"], c
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_edge_cases(backend, request):
+    """Empty batch, axis-parallel rays (zero direction components), rays that miss everything, unnormalised
+    directions, and a scene whose only primitives share one leaf."""
+    sd = scene("cornell_pinhole")
+    o = _oracle(sd)
+    b = make_backend(backend, sd, request)
+    got, _ = b.intersect(np.zeros((0, 6)))
+    assert len(got) == 0
+    rays = np.array([
+        [0.3, 5.0, 2.0, 0.0, 0.0, -1.0],     # axis parallel, hits the back wall
+        [0.3, 5.0, 2.0, 0.0, -1.0, 0.0],     # straight down onto the floor
+        [0.3, 5.0, 2.0, 0.0, 0.0, 1.0],      # out through the open front: miss
+        [0.3, 5.0, 2.0, 0.0, 0.0, -3.0],     # unnormalised direction: t scales by 1/3
+        [0.1, 5.0, 24.0, 0.0, 0.0, -1.0],    # from beside the camera (the wall's centre is on its diagonal: a tie)
+        [20.0, 20.0, 20.0, 1.0, 0.0, 0.0],   # outside, pointing away
+        [0.25, 9.0, 0.5, 0.0, 1.0, 0.0],     # up into the light (off the quad's diagonal)
+    ])
+    ref, _ = o.intersect(rays)
+    got, _ = b.intersect(rays)
+    assert ref["hit"].tolist() == got["hit"].tolist() == [1, 1, 0, 1, 1, 0, 1]
+    m = ref["hit"] == 1
+    assert (ref["id"][m] == got["id"][m]).all()
+    assert np.allclose(ref["t"][m], got["t"][m], rtol=1e-5)
+    assert got["id"][6] in (8, 9)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_tiny_scenes(backend, request):
+    """One triangle, one sphere, and an empty scene: the flattened tree degenerates to a single leaf."""
+    from pathtracer_amd import scenes
+    rays = _f32_rays(raygen.interior_rays(2000, 3, lo=(-2, -2, 3), hi=(2, 2, 6)))
+    rays[:, 3:] = np.array([0.0, 0.0, -1.0]) + 0.2 * rays[:, 3:]
+    for kind in ("tri", "sphere", "empty"):
+        sd = scenes.SceneData()
+        m = sd.add_material(scenes.Material())
+        if kind == "tri":
+            sd.add_triangles([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.tile([0, 0, 1.0], (1, 3, 1)), np.zeros((1, 3, 2)), m)
+        elif kind == "sphere":
+            sd.add_sphere((0, 0, 0), 1.0, m)
+        sd.camera = scenes.CameraDesc(16, 16)
+        o = _oracle(sd)
+        b = make_backend(backend, sd, request)
+        ref, _ = o.intersect(rays)
+        got, _ = b.intersect(rays)
+        c = parity.classify_hits(sd, rays, ref, got)
+        # a single flat triangle is a zero-thickness box in the reference's tree: it rejects it (ref_miss)
+        assert c["unexplained"] == 0 and c["tie"] == 0 and c["graze"] <= 2, (kind, c)
+        if kind == "sphere":
+            assert c["ok"] == c["n"], c
+        if kind == "empty":
+            assert (got["hit"] == 0).all()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fewer_tests_than_reference(backend, request):
+    """The kernels' tree must not need more box or primitive tests per query than the reference's tree does
+    (so a worse tree cannot inflate a bytes-per-ray roofline)."""
+    for name in ("cornell", "mesh"):
+        sd = scene(name)
+        o = _oracle(sd)
+        b = make_backend(backend, sd, request)
+        rays = _f32_rays(raygen.interior_rays(20000, 11))
+        _, cref = o.intersect(rays)
+        _, cgot = b.intersect(rays)
+        print(name, cref, cgot)
+        assert cgot["prim_tests"] <= cref["prim_tests"]
+        if name == "mesh":
+            assert cgot["box_tests"] <= cref["box_tests"]

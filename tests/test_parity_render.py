@@ -1,0 +1,131 @@
+"""Second correctness check: rendered images (linear accumulation buffer) match the oracle.
+
+The kernels and the oracle draw the same counter-based random numbers, so for most pixels the two follow the
+same paths and differ only by fp32 rounding; a small fraction of paths takes a different branch somewhere
+(a hit across an edge, a Russian-roulette or Fresnel decision within rounding of its threshold) and then the
+pixel differs by Monte-Carlo noise.  Three bars, all stated here:
+
+  * per-channel image mean within 1 % of the oracle's (bias check);
+  * RMSE (after clamping to [0,4]) <= 1.5 x RMSE0, where RMSE0 is oracle-vs-oracle at the same sample
+    count with another seed (the noise floor the reference itself has from run to run);
+  * at most 6 % of pixels differ by more than 1e-2 in any channel (same random numbers => same paths).
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from pathtracer_amd import native
+from tests import parity
+from tests.backends import BACKENDS, make_backend, scene
+
+CASES = [
+    # scene, samples, max_bounce
+    ("cornell", 32, 3),          # the reference's own CPU-runnable configuration, scaled down
+    ("cornell_pinhole", 16, 5),  # Russian roulette active (depth > 3)
+    ("mesh", 16, 3),             # mesh + glass sphere + mirror sphere
+    ("glass", 24, 8),            # dielectric mesh, 8 bounces
+    ("envmap", 24, 3),           # environment map + textured floor + depth of field
+    ("sky", 24, 4),              # sky gradient, fuzzy specular, microfacet, sphere light
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("name,spp,bounces", CASES)
+def test_image_matches_oracle(backend, name, spp, bounces, request):
+    sd = scene(name)
+    o = orc.OracleScene(sd)
+    b = make_backend(backend, sd, request)
+    ref, cref = o.render(spp, bounces, seed=11)
+    ref2, _ = o.render(spp, bounces, seed=12)
+    got, cgot = b.render(spp, bounces, seed=11)
+    assert np.isfinite(got).all() == np.isfinite(ref).all()
+    st = parity.image_stats(ref, got)
+    noise = parity.image_stats(ref, ref2)
+    print(name, st, "noise rmse", noise["rmse"])
+    assert st["mean_rel"] <= 0.01, st
+    assert st["rmse"] <= 1.5 * noise["rmse"], (st, noise)
+    assert st["frac_diff"] <= 0.06, st
+    # same paths => nearly the same amount of work
+    assert cgot["camera_rays"] == cref["camera_rays"]
+    assert abs(cgot["segments"] - cref["segments"]) <= 0.005 * cref["segments"], (cgot, cref)
+    assert cgot["queries"] <= cref["queries"]  # shadow rays from a light to itself are not traced
+    assert cgot["queries"] >= 0.97 * cref["queries"], (cgot, cref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_converged_image(backend, request):
+    """Higher sample count on the small Cornell box: tonemapped 8-bit output within 2 levels on average."""
+    sd = scene("cornell")
+    o = orc.OracleScene(sd)
+    b = make_backend(backend, sd, request)
+    ref, _ = o.render(256, 3, seed=3)
+    got, _ = b.render(256, 3, seed=3)
+    a8 = orc.tonemap_u8(ref).astype(np.int32)
+    b8 = orc.tonemap_u8(got).astype(np.int32)
+    mad = np.abs(a8 - b8).mean()
+    print("mean abs 8-bit diff", mad)
+    assert mad <= 2.0
+    st = parity.image_stats(ref, got)
+    assert st["mean_rel"] <= 0.01, st
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_flags(backend, request):
+    """Each config switch (src/config.h:3-8) changes the kernels the same way it changes the oracle."""
+    sd = scene("sky")
+    o = orc.OracleScene(sd)
+    b = make_backend(backend, sd, request)
+    variants = {
+        "debug_normal": dict(debug_normal=1),
+        "no_rr": dict(russian_roulette=0),
+        "no_direct": dict(direct_light_sampling=0),
+        "no_indirect": dict(indirect_light_sampling=0),
+        "no_importance": dict(importance_sample=0),
+        "no_hemisphere_check": dict(check_hemisphere=0),
+    }
+    for label, kw in variants.items():
+        fo = orc.lib().orc_default_flags()
+        fk = native.PtkFlags.defaults()
+        for k, v in kw.items():
+            setattr(fo, k, v)
+            setattr(fk, k, v)
+        ref, _ = o.render(12, 6, seed=5, flags=fo)
+        got, _ = b.render(12, 6, seed=5, flags=fk)
+        st = parity.image_stats(ref, got)
+        print(label, st)
+        assert st["mean_rel"] <= 0.02, (label, st)
+        assert st["frac_diff"] <= 0.08, (label, st)
+        assert st["frac_nonfinite_mismatch"] <= 0.02, (label, st)
+        if label == "debug_normal":
+            assert st["rmse"] < 1e-3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_frame_splits_give_the_same_samples(backend, request):
+    """A frame split by rows is bit-identical to the unsplit frame; split by sample index (stride 2, as two
+    GPUs would) or into successive batches (Renderer::render called repeatedly, src/main.cpp:242-252) it is the
+    same sample set, equal up to fp32 summation order."""
+    sd = scene("cornell")
+    b = make_backend(backend, sd, request)
+    h = sd.camera.height
+    full, _ = b.render(8, 3, seed=9)
+    top, _ = b.render(8, 3, seed=9, row_begin=0, row_end=h // 2 + 3)
+    both, _ = b.render(8, 3, seed=9, row_begin=h // 2 + 3, row_end=h, reset=False)
+    assert np.array_equal(full, both)
+    assert np.array_equal(top[: h // 2 + 3], full[: h // 2 + 3]) and not top[h // 2 + 3:].any()
+    b.render(4, 3, seed=9, sample_first=0, sample_stride=2)
+    strided, _ = b.render(4, 3, seed=9, sample_first=1, sample_stride=2, reset=False)
+    assert np.allclose(strided, full, rtol=1e-5, atol=1e-6)
+    b.render(5, 3, seed=9, sample_first=0)
+    batched, _ = b.render(3, 3, seed=9, sample_first=5, reset=False)
+    assert np.allclose(batched, full, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_zero_work(backend, request):
+    sd = scene("cornell")
+    b = make_backend(backend, sd, request)
+    img, cnt = b.render(0, 3, seed=1)
+    assert not img.any() and cnt["segments"] == 0
+    img, cnt = b.render(4, 0, seed=1)  # max_bounce 0: trace_ray returns black at once (src/renderer.cpp:59-61)
+    assert not img.any() and cnt["segments"] == 0 and cnt["camera_rays"] == 4 * sd.camera.width * sd.camera.height

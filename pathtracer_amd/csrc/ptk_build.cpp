@@ -298,6 +298,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
       l.area = (float)(0.5 * std::sqrt(cx * cx + cy * cy + cz * cz));
       for (int k = 0; k < 3; k++) {
         l.p0[k] = (float)p[k]; l.p1[k] = (float)p[3 + k]; l.p2[k] = (float)p[6 + k];
+        l.n0[k] = (float)nr[k]; l.n1[k] = (float)nr[3 + k]; l.n2[k] = (float)nr[6 + k];
         l.emission[k] = out.materials[mat].emission[k];
       }
       out.lights.push_back(l);
@@ -337,7 +338,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
 
   // Boxes are widened by a few ulps of the largest coordinate: the fp32 slab test and the fp32
   // triangle test round independently, and a hit on a box face must not be lost to that.
-  const float pad = (float)(max_abs * 8e-7);
+  const float pad = (float)(max_abs * 2e-6);
   for (auto& b : boxes)
     for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
 

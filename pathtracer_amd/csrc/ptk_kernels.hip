@@ -23,11 +23,25 @@ namespace ptk {
 constexpr int kBlock = 256;
 constexpr int kTile = 16;
 
+// Wave scheduling knobs of the render kernel (see its main loop).
+// Measured on the 81,920-triangle mesh scene (1024x1024, 64 spp, 3 bounces; Mrays/s): strict
+// while-while (descend 1) 2.5k; descend 16 / refill 32 3.4k; descend 32 3.2k; descend 64 2.6k.
+#ifndef PTK_DESCEND_MIN
+#define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
+#endif
+#ifndef PTK_REFILL_MIN
+#define PTK_REFILL_MIN 32   // shade / refill once at least this many lanes have a finished query
+#endif
+#ifndef PTK_MIN_WAVES
+#define PTK_MIN_WAVES 4     // __launch_bounds__ waves per SIMD for the render kernel (3: 3.47k, 4: 3.79k, 5: 3.03k Mrays/s)
+#endif
+constexpr int kDescendMin = PTK_DESCEND_MIN;
+constexpr int kRefillMin = PTK_REFILL_MIN;
+
 struct LdsStack {
   uint32_t* base;  // this lane's column of the workgroup's LDS array
   int sp;
-  __device__ __forceinline__ void reset() { sp = 0; }
-  __device__ __forceinline__ bool empty() const { return sp == 0; }
+  __device__ __forceinline__ void reset() { base[0] = (uint32_t)kTravDone; sp = 1; }
   __device__ __forceinline__ void push(uint32_t v)
   {
     if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // the builder keeps trees shallower than the stack
@@ -73,7 +87,7 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void render_kernel(SceneView sc, CameraView cam, FlagView fl, RenderArgs ra,
+__global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView sc, CameraView cam, FlagView fl, RenderArgs ra,
                                                         f4* __restrict__ accum, unsigned long long* counters)
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
@@ -88,15 +102,38 @@ __global__ __launch_bounds__(kBlock) void render_kernel(SceneView sc, CameraView
   int py = ra.row_begin + ty * kTile + (wave >> 1) * 8 + (lane >> 3);
 
   Counters cnt = {0, 0, 0, 0, 0};
-  if (px < cam.width && py < ra.row_end) {
-    v3 sum = V3(0.f, 0.f, 0.f);
-    for (int s = 0; s < ra.samples; s++) {
-      uint32_t sample = (uint32_t)(ra.sample_first + s * ra.sample_stride);
-      sum += trace_path<LdsStack, STATS>(sc, cam, fl, ra.max_bounce, px, py, sample, ra.seed, st, cnt);
+  const bool in_image = px < cam.width && py < ra.row_end;
+  PathParams pp;
+  pp.px = px; pp.py = py; pp.samples = ra.samples; pp.max_bounce = ra.max_bounce;
+  pp.sample_first = ra.sample_first; pp.sample_stride = ra.sample_stride; pp.seed = ra.seed;
+  PathState ps;
+  path_init(ps, st, sc, cam, pp, in_image, cnt);
+
+  // Every lane keeps one query in flight.  The wave alternates three uniform phases:
+  //   descend  - lanes at an inner node visit it, until no lane (or too few lanes) are at one;
+  //   leaves   - lanes at a leaf intersect its primitives;
+  //   advance  - once enough lanes have a finished query, they shade and start their next one,
+  //              while the rest keep their traversal state (node in a register, stack in LDS).
+  for (;;) {
+    for (;;) {
+      bool want = trav_at_inner(ps.tr);
+      if (__popcll(__ballot(want)) < kDescendMin) break;
+      if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
+    if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    else if (kDescendMin > 1 && trav_at_inner(ps.tr)) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    bool ready = ps.alive && trav_done(ps.tr);
+    unsigned long long ready_mask = __ballot(ready);
+    unsigned long long busy_mask = __ballot(!trav_done(ps.tr));
+    if ((ready_mask | busy_mask) == 0ull) break;
+    if (__popcll(ready_mask) >= kRefillMin || busy_mask == 0ull) {
+      if (ready) path_advance(ps, st, sc, cam, fl, pp, cnt);
+    }
+  }
+  if (in_image) {
     size_t i = (size_t)py * (size_t)cam.width + (size_t)px;
     f4 a = accum[i];
-    a.x += sum.x; a.y += sum.y; a.z += sum.z; a.w += (float)ra.samples;
+    a.x += ps.sum.x; a.y += ps.sum.y; a.z += ps.sum.z; a.w += (float)ra.samples;
     accum[i] = a;
   }
   flush_counters(cnt, counters);

@@ -71,8 +71,10 @@ struct alignas(16) LightRec {
   float radius;
   float p0[3], p1[3], p2[3];  // triangle vertices; sphere: p0 = centre
   float emission[3];
+  float n0[3], n1[3], n2[3];  // triangle vertex normals
+  float pad[3];
 };
-static_assert(sizeof(LightRec) == 64, "LightRec is 64 bytes");
+static_assert(sizeof(LightRec) == 112, "LightRec is 112 bytes");
 
 struct alignas(16) TextureRec {
   uint64_t offset;  // byte offset of the first texel in the texel pool

@@ -255,110 +255,244 @@ PTK_HD v3 bsdf_eval(const FlagView& fl, const MaterialRec& m, v3 albedo, v3 V, v
 
 PTK_HD float luma(v3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }  // src/renderer.cpp:55
 
-// ---------------------------------------------------------------- next-event estimation
-// Renderer::sample_lights, src/renderer.cpp:130-171.  One uniformly chosen emissive primitive,
-// weight = area * cos(light) / dist^2 * light_count, BSDF evaluated in the LIGHT's frame,
-// no cosine at the shading point and no 1/pi: all as the reference does it.
-template <class Stack, bool STATS>
-PTK_HD v3 sample_lights(const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s, v3 albedo,
-                        v3 incoming, Rng& g, Stack& st, Counters& cnt)
+// ---------------------------------------------------------------- the path, as a per-lane state machine
+// Renderer::trace_ray (src/renderer.cpp:57-126) is a recursion whose every level makes up to two
+// closest-hit queries: the path segment itself and one shadow ray (Renderer::sample_lights,
+// src/renderer.cpp:130-171).  Here a lane owns one pixel and carries its path as explicit state,
+// so that ALL its queries -- whatever the bounce, segment or shadow -- run through one traversal
+// loop shared by the wave.  advance() is called whenever the lane's query has finished; it
+// consumes the result and sets up the lane's next query:
+//
+//   segment finished, miss      -> add background, path ends
+//   segment finished, hit       -> Russian roulette, BSDF sample, emission, pick a light;
+//                                  next query = shadow ray (if a light was sampled) else next segment
+//   shadow ray finished         -> add the light's contribution if the light is what was hit;
+//                                  next query = next segment
+//   path ends                   -> accumulate, start the next sample's camera ray (or retire)
+//
+// The arithmetic in recursion order: with beta the product of rr_weight * BSDF value along the
+// path, a level contributes beta * rr_weight * (emission + direct) and a Russian-roulette kill
+// contributes beta * emission, exactly the values the reference's recursion returns.
+struct PathState {
+  Traversal tr;        // the query in flight
+  Rng g;
+  v3 beta, L, sum;
+  v3 pending;          // shadow ray in flight: radiance to add if it reaches the light
+  v3 next_d;           // shadow ray in flight: direction of the path segment that follows it
+  uint32_t light_id;   // shadow ray in flight: the light it must reach
+  uint32_t origin_id;  // primitive the current path vertex lies on
+  int32_t sample;      // samples finished so far
+  int32_t depth;
+  bool shadow;         // the query in flight is a shadow ray
+  bool prev_specular;
+  bool alive;          // false once all samples are done
+};
+
+struct PathParams {
+  int32_t px, py, samples, max_bounce, sample_first, sample_stride;
+  uint32_t seed;
+};
+
+template <class Stack>
+PTK_HD void path_begin_sample(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
+                              const PathParams& pp, Counters& cnt)
 {
-  v3 zero = V3(0.0f, 0.0f, 0.0f);
-  if (sc.n_lights == 0) return zero;
-  int idx = (int)(rnd(g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
+  // a max_bounce of 0 makes every sample black without a single query (src/renderer.cpp:59-61)
+  while (ps.sample < pp.samples) {
+    uint32_t index = (uint32_t)(pp.sample_first + ps.sample * pp.sample_stride);
+    ps.g = rng_init(pp.seed, (uint32_t)(pp.py * cam.width + pp.px), index);
+    v3 o, d;
+    camera_ray(cam, pp.px, pp.py, ps.g, o, d);
+    cnt.camera_rays++;
+    if (pp.max_bounce <= 0) { ps.sample++; continue; }
+    ps.L = V3(0.0f, 0.0f, 0.0f);
+    ps.beta = V3(1.0f, 1.0f, 1.0f);
+    ps.prev_specular = false;
+    ps.shadow = false;
+    ps.depth = 0;
+    ps.origin_id = kNoPrim;
+    cnt.segments++;
+    cnt.queries++;
+    trav_begin(ps.tr, st, sc, o, d, kTMax, kNoPrim);
+    return;
+  }
+  ps.alive = false;
+  ps.tr.node = kTravDone;
+}
+
+template <class Stack>
+PTK_HD void path_init(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam, const PathParams& pp,
+                      bool in_image, Counters& cnt)
+{
+  ps.sum = V3(0.0f, 0.0f, 0.0f);
+  ps.L = ps.beta = ps.pending = ps.next_d = V3(0.0f, 0.0f, 0.0f);
+  ps.light_id = ps.origin_id = kNoPrim;
+  ps.sample = 0;
+  ps.depth = 0;
+  ps.shadow = ps.prev_specular = false;
+  ps.alive = in_image;
+  ps.tr.node = kTravDone;
+  if (in_image) path_begin_sample(ps, st, sc, cam, pp, cnt);
+}
+
+template <class Stack>
+PTK_HD void path_end_sample(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
+                            const PathParams& pp, Counters& cnt)
+{
+  ps.sum += ps.L;
+  ps.sample++;
+  path_begin_sample(ps, st, sc, cam, pp, cnt);
+}
+
+// Start the path segment that leaves the current vertex in direction d (or end the path at the bounce limit).
+template <class Stack>
+PTK_HD void path_next_segment(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
+                              const PathParams& pp, const FlagView& fl, v3 d, Counters& cnt)
+{
+  ps.depth++;
+  if (!fl.indirect_light_sampling || ps.depth >= pp.max_bounce) {
+    path_end_sample(ps, st, sc, cam, pp, cnt);
+    return;
+  }
+  ps.shadow = false;
+  cnt.segments++;
+  cnt.queries++;
+  trav_begin(ps.tr, st, sc, ps.tr.o, d, kTMax, ps.origin_id);
+}
+
+// Next-event estimation set-up, Renderer::sample_lights (src/renderer.cpp:130-171): one uniformly chosen
+// emissive primitive, weight = area * cos(light) / dist^2 * light_count, BSDF evaluated in the LIGHT's
+// frame, no cosine at the shading point and no 1/pi -- all as the reference does it.  Everything except
+// the visibility query is evaluated here; the result waits in ps.pending until the shadow ray returns.
+// Returns false when no shadow ray is needed.
+PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s,
+                      v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out)
+{
+  if (sc.n_lights == 0) return false;
+  int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
   if (idx > sc.n_lights - 1) idx = sc.n_lights - 1;
   const LightRec light = sc.lights[idx];
-  float r1 = rnd(g), r2 = rnd(g);
-  v3 q;
+  float r1 = rnd(ps.g), r2 = rnd(ps.g);
+  v3 q, normal;
   if (light.kind == kTriangle) {  // Primitive::sample_point, src/geometry.cpp:228-241
     float t = sqrtf(r1);
     float u = 1.0f - t, v = r2 * t, w = 1.0f - u - v;
     q = ld3(light.p0) * u + ld3(light.p1) * v + ld3(light.p2) * w;
+    // what the shadow ray's hit record will carry: a light keeps its interpolated, unflipped normal
+    normal = ld3(light.n0) * u + ld3(light.n1) * v + ld3(light.n2) * w;
   } else {
     v3 c = ld3(light.p0);
     v3 n = normalize(s.point - c);
-    v3 d = unit_vector_from(r1, r2);
-    if (!(dot(d, n) > 0.0f)) d = -d;
-    q = c + d * light.radius;
+    v3 dir = unit_vector_from(r1, r2);
+    if (!(dot(dir, n) > 0.0f)) dir = -dir;
+    q = c + dir * light.radius;
+    normal = dir;  // refined below
   }
   v3 to_light = q - s.point;
   float distance = length(to_light);
   to_light = to_light * (1.0f / distance);
-  if (s.id == light.id) return zero;  // src/renderer.cpp:146 (the reference traces the ray first; the result is unused)
-  cnt.queries++;
-  // The light is at `distance`; nothing farther can be the closest hit that counts.
-  Hit hit;
-  if (!closest_hit<Stack, STATS>(sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, st, hit, cnt)) return zero;
-  if (hit.id != light.id) return zero;
-  Surface ls;
-  make_surface(sc, s.point, to_light, hit, ls);
-  v3 normal = ls.normal;
+  if (s.id == light.id) return false;  // src/renderer.cpp:146 (the reference traces the ray first; the result is unused)
+  if (light.kind == kSphere) {
+    // The shadow ray meets the sphere at its FIRST intersection, which is not the sampled point when that
+    // point lies beyond the silhouette; the hit record's normal is taken there and faces the ray.
+    v3 oc = ld3(light.p0) - s.point;
+    float h = dot(to_light, oc);
+    v3 l = oc - to_light * h;
+    float disc = light.radius * light.radius - dot(l, l);
+    float t = h - sqrtf(fmaxf(disc, 0.0f));
+    if (!(t > kTMin)) t = h + sqrtf(fmaxf(disc, 0.0f));
+    normal = ((s.point + to_light * t) - ld3(light.p0)) * (1.0f / light.radius);
+    if (dot(to_light, normal) > 0.0f) normal = -normal;
+  }
   Frame fr = make_frame(normal);
   v3 wo = to_local(fr, -incoming);
   v3 wi = to_local(fr, to_light);
   float light_cos = fmaxf(dot(normal, -to_light), 0.0f);
   float weight = light.area * light_cos / (distance * distance);
   v3 f = bsdf_eval(fl, m, albedo, wo, wi);
-  return ld3(light.emission) * f * (weight * (float)sc.n_lights);
+  ps.pending = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
+  ps.light_id = light.id;
+  to_light_out = to_light;
+  distance_out = distance;
+  return true;
 }
 
-// ---------------------------------------------------------------- the path
-// One camera sample: Camera::get_ray + Renderer::trace_ray(ray, 0).
-template <class Stack, bool STATS>
-PTK_HD v3 trace_path(const SceneView& sc, const CameraView& cam, const FlagView& fl, int max_bounce, int px, int py,
-                     uint32_t sample, uint32_t seed, Stack& st, Counters& cnt)
+// The lane's query has finished: consume it and set up the next one.
+template <class Stack>
+PTK_HD void path_advance(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam, const FlagView& fl,
+                         const PathParams& pp, Counters& cnt)
 {
-  Rng g = rng_init(seed, (uint32_t)(py * cam.width + px), sample);
-  v3 o, d;
-  camera_ray(cam, px, py, g, o, d);
-  cnt.camera_rays++;
-  v3 L = V3(0.0f, 0.0f, 0.0f);
-  v3 beta = V3(1.0f, 1.0f, 1.0f);
-  bool prev_specular = false;
-  uint32_t origin_id = kNoPrim;
-  for (int depth = 0; depth < max_bounce; depth++) {
-    cnt.segments++;
-    cnt.queries++;
-    Hit hit;
-    if (!closest_hit<Stack, STATS>(sc, o, d, kTMax, origin_id, st, hit, cnt)) {
-      L += beta * background(sc, d);
-      break;
-    }
-    Surface s;
-    make_surface(sc, o, d, hit, s);
-    const MaterialRec m = sc.materials[s.material];
-    if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
-      L += beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
-      break;
-    }
-    v3 albedo = surface_albedo(sc, m, s);
-    v3 emission = ld3(m.emission);
-    float rr_weight = 1.0f;
-    if (fl.russian_roulette && depth > 3) {  // src/renderer.cpp:78-90
-      float p = luma(albedo);
-      if (rnd(g) >= p) {
-        L += beta * emission;
-        break;
-      }
-      rr_weight = 1.0f / p;
-    }
-    Frame fr = make_frame(s.normal);
-    v3 wo = to_local(fr, -d);
-    v3 wi = bsdf_sample(fl, m, s.inside, wo, g);
-    bool specular = (m.flags & kMatSpecular) != 0;
-    v3 radiance = V3(0.0f, 0.0f, 0.0f);
-    if (!fl.direct_light_sampling || depth == 0 || specular || prev_specular) radiance += emission;
-    if (fl.direct_light_sampling && !specular)
-      radiance += sample_lights<Stack, STATS>(sc, fl, m, s, albedo, d, g, st, cnt);
-    L += beta * radiance * rr_weight;
-    if (!fl.indirect_light_sampling) break;
-    beta *= bsdf_eval(fl, m, albedo, wo, wi) * rr_weight;
-    o = s.point;
-    d = to_world(fr, wi);  // not renormalised, as in the reference (src/renderer.cpp:121)
-    origin_id = s.id;
-    prev_specular = specular;
+  if (ps.shadow) {
+    if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
+    path_next_segment(ps, st, sc, cam, pp, fl, ps.next_d, cnt);
+    return;
   }
-  return L;
+  const v3 o = ps.tr.o, d = ps.tr.d;
+  if (ps.tr.hit.id == kNoPrim) {
+    ps.L += ps.beta * background(sc, d);  // src/renderer.cpp:67-69
+    path_end_sample(ps, st, sc, cam, pp, cnt);
+    return;
+  }
+  Surface s;
+  make_surface(sc, o, d, ps.tr.hit, s);
+  const MaterialRec m = sc.materials[s.material];
+  if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
+    ps.L += ps.beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
+    path_end_sample(ps, st, sc, cam, pp, cnt);
+    return;
+  }
+  v3 albedo = surface_albedo(sc, m, s);
+  v3 emission = ld3(m.emission);
+  float rr_weight = 1.0f;
+  if (fl.russian_roulette && ps.depth > 3) {  // src/renderer.cpp:78-90
+    float p = luma(albedo);
+    if (rnd(ps.g) >= p) {
+      ps.L += ps.beta * emission;
+      path_end_sample(ps, st, sc, cam, pp, cnt);
+      return;
+    }
+    rr_weight = 1.0f / p;
+  }
+  Frame fr = make_frame(s.normal);
+  v3 wo = to_local(fr, -d);
+  v3 wi = bsdf_sample(fl, m, s.inside, wo, ps.g);
+  bool specular = (m.flags & kMatSpecular) != 0;
+  v3 scale = ps.beta * rr_weight;
+  if (!fl.direct_light_sampling || ps.depth == 0 || specular || ps.prev_specular) ps.L += scale * emission;
+  v3 next_d = to_world(fr, wi);  // not renormalised, as in the reference (src/renderer.cpp:121)
+  ps.beta = scale * bsdf_eval(fl, m, albedo, wo, wi);
+  ps.prev_specular = specular;
+  ps.origin_id = s.id;
+  ps.tr.o = s.point;
+  v3 to_light;
+  float distance;
+  if (fl.direct_light_sampling && !specular && nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance)) {
+    ps.shadow = true;
+    ps.next_d = next_d;
+    cnt.queries++;
+    // the light is at `distance`: nothing farther can be the closest hit that counts
+    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id);
+    return;
+  }
+  path_next_segment(ps, st, sc, cam, pp, fl, next_d, cnt);
+}
+
+// One lane run to completion on its own (the host-compiled checks use this; the kernel interleaves
+// the same steps across a wave).
+template <class Stack, bool STATS>
+PTK_HD v3 render_pixel(const SceneView& sc, const CameraView& cam, const FlagView& fl, const PathParams& pp, Stack& st,
+                       Counters& cnt)
+{
+  PathState ps;
+  path_init(ps, st, sc, cam, pp, true, cnt);
+  while (ps.alive) {
+    while (!trav_done(ps.tr)) {
+      if (trav_at_inner(ps.tr)) trav_inner<Stack, STATS>(ps.tr, st, sc, cnt);
+      else trav_leaf<Stack, STATS>(ps.tr, st, sc, cnt);
+    }
+    path_advance(ps, st, sc, cam, fl, pp, cnt);
+  }
+  return ps.sum;
 }
 
 }  // namespace ptk

@@ -87,67 +87,113 @@ PTK_HD bool hit_sphere(const PrimRec& p, v3 o, v3 d, float tbest, bool own_surfa
 // Slab test of one child box against [0, tbest]; returns entry distance in tn.
 // fminf/fmaxf drop NaNs from 0 * inf, so an axis-parallel ray lying exactly in a box face
 // is kept on that axis (the reference's comparisons do the same, src/aabb.cpp:54-62).
-PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float hiz, v3 o, v3 inv, float tbest,
+// Plane distances are formed as fma(plane, 1/d, -(o/d)): one instruction per plane.  The caller keeps 1/d
+// finite (axis-parallel rays get +-1e20), so a slab the origin lies in gives -huge..+huge and a slab it lies
+// outside gives two huge values of one sign.  The rounding of o/d is covered by the padding the builder puts
+// on every box.
+PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float hiz, v3 oi, v3 inv, float tbest,
                     float& tn)
 {
-  float tx0 = (lox - o.x) * inv.x, tx1 = (hix - o.x) * inv.x;
-  float ty0 = (loy - o.y) * inv.y, ty1 = (hiy - o.y) * inv.y;
-  float tz0 = (loz - o.z) * inv.z, tz1 = (hiz - o.z) * inv.z;
+  float tx0 = fmaf(lox, inv.x, -oi.x), tx1 = fmaf(hix, inv.x, -oi.x);
+  float ty0 = fmaf(loy, inv.y, -oi.y), ty1 = fmaf(hiy, inv.y, -oi.y);
+  float tz0 = fmaf(loz, inv.z, -oi.z), tz1 = fmaf(hiz, inv.z, -oi.z);
   float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
   float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
   tn = tnear;
   return tnear <= tfar * 1.0000005f;  // a few ulps of slack: boxes of axis-aligned walls have zero thickness
 }
 
-// Stack: push(uint32_t), pop() -> uint32_t, empty(), reset().
-// skip_id: primitive the ray starts on (kNoPrim for none).
+// ---------------------------------------------------------------------------------
+// Resumable traversal.  A lane's query is a small state (ray, closest hit so far, current
+// node) plus its stack; trav_inner() visits one inner node, trav_leaf() intersects one leaf.
+// Splitting the work this way lets a wave run "all lanes descend" and "all lanes intersect"
+// as separate uniform loops, and lets a lane whose query has finished pick up its next ray
+// while its neighbours are still traversing.
+//
+// Stack: reset(), push(uint32_t), pop() -> uint32_t.  reset() leaves kTravDone at the bottom,
+// so popping an exhausted stack yields the "finished" node.
+constexpr int32_t kTravDone = (int32_t)0x80000000;  // not a valid leaf code for < 2^28 primitives
+
+struct Traversal {
+  v3 o, d, inv, oi;  // oi = o * inv (origin in plane-distance units)
+  Hit hit;
+  int32_t node;      // >= 0 inner node, kTravDone finished, other negative values: leaf
+  uint32_t skip_id;  // primitive the ray starts on (kNoPrim for none)
+};
+
+PTK_HD bool trav_done(const Traversal& tr) { return tr.node == kTravDone; }
+PTK_HD bool trav_at_inner(const Traversal& tr) { return tr.node >= 0; }
+PTK_HD bool trav_at_leaf(const Traversal& tr) { return tr.node < 0 && tr.node != kTravDone; }
+
+template <class Stack>
+PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id)
+{
+  tr.o = o; tr.d = d;
+  // 1/d is kept finite: with an infinite 1/d the fused form below would turn "inf - inf" into NaN for one
+  // plane of a slab that contains the origin.  1e20 keeps every product far inside the float range.
+  const float big = 1e20f;
+  tr.inv = V3(fmaxf(fminf(1.0f / d.x, big), -big), fmaxf(fminf(1.0f / d.y, big), -big),
+              fmaxf(fminf(1.0f / d.z, big), -big));
+  tr.oi = o * tr.inv;
+  tr.hit.t = tmax;
+  tr.hit.id = kNoPrim;
+  tr.hit.kind = kTriangle;
+  tr.hit.u = tr.hit.v = 0.0f;
+  tr.skip_id = skip_id;
+  st.reset();
+  tr.node = sc.n_prims > 0 ? 0 : kTravDone;
+}
+
+template <class Stack, bool STATS>
+PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+{
+  const NodePair n = sc.nodes[tr.node];
+  float tn0, tn1;
+  bool h0 = hit_box(n.xy0.x, n.xy0.y, n.xy0.z, n.xy0.w, n.zz.x, n.zz.y, tr.oi, tr.inv, tr.hit.t, tn0);
+  bool h1 = hit_box(n.xy1.x, n.xy1.y, n.xy1.z, n.xy1.w, n.zz.z, n.zz.w, tr.oi, tr.inv, tr.hit.t, tn1);
+  if (STATS) cnt.box_tests += 2;
+  if (h0 && h1) {
+    bool swap = tn1 < tn0;
+    st.push((uint32_t)(swap ? n.child0 : n.child1));
+    tr.node = swap ? n.child1 : n.child0;
+  } else if (h0) tr.node = n.child0;
+  else if (h1) tr.node = n.child1;
+  else tr.node = (int32_t)st.pop();
+}
+
+template <class Stack, bool STATS>
+PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+{
+  uint32_t leaf = ~(uint32_t)tr.node;
+  uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+  for (uint32_t i = 0; i < count; i++) {
+    const PrimRec p = sc.prims[first + i];
+    uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
+    if (STATS) cnt.prim_tests++;
+    if (kind == kTriangle) {
+      if (id == tr.skip_id) continue;
+      float t, u, v;
+      if (hit_triangle(p, tr.o, tr.d, tr.hit.t, t, u, v)) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = u; tr.hit.v = v; }
+    } else {
+      float t;
+      if (hit_sphere(p, tr.o, tr.d, tr.hit.t, id == tr.skip_id, t)) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = tr.hit.v = 0.0f; }
+    }
+  }
+  tr.node = (int32_t)st.pop();
+}
+
+// One whole query on one lane (used where rays are independent: the ray-batch entry point).
 template <class Stack, bool STATS>
 PTK_HD bool closest_hit(const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id, Stack& st, Hit& hit,
                         Counters& cnt)
 {
-  hit.t = tmax;
-  hit.id = kNoPrim;
-  hit.kind = kTriangle;
-  hit.u = hit.v = 0.0f;
-  if (sc.n_prims <= 0) return false;
-  v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  st.reset();
-  int32_t node = 0;
-  for (;;) {
-    if (node >= 0) {
-      const NodePair n = sc.nodes[node];
-      float tn0, tn1;
-      bool h0 = hit_box(n.xy0.x, n.xy0.y, n.xy0.z, n.xy0.w, n.zz.x, n.zz.y, o, inv, hit.t, tn0);
-      bool h1 = hit_box(n.xy1.x, n.xy1.y, n.xy1.z, n.xy1.w, n.zz.z, n.zz.w, o, inv, hit.t, tn1);
-      if (STATS) cnt.box_tests += 2;
-      if (h0 && h1) {
-        bool swap = tn1 < tn0;
-        st.push((uint32_t)(swap ? n.child0 : n.child1));
-        node = swap ? n.child1 : n.child0;
-        continue;
-      }
-      if (h0) { node = n.child0; continue; }
-      if (h1) { node = n.child1; continue; }
-    } else {
-      uint32_t leaf = ~(uint32_t)node;
-      uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-      for (uint32_t i = 0; i < count; i++) {
-        const PrimRec p = sc.prims[first + i];
-        uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
-        if (STATS) cnt.prim_tests++;
-        if (kind == kTriangle) {
-          if (id == skip_id) continue;
-          float t, u, v;
-          if (hit_triangle(p, o, d, hit.t, t, u, v)) { hit.t = t; hit.id = id; hit.kind = kind; hit.u = u; hit.v = v; }
-        } else {
-          float t;
-          if (hit_sphere(p, o, d, hit.t, id == skip_id, t)) { hit.t = t; hit.id = id; hit.kind = kind; hit.u = hit.v = 0.0f; }
-        }
-      }
-    }
-    if (st.empty()) break;
-    node = (int32_t)st.pop();
+  Traversal tr;
+  trav_begin(tr, st, sc, o, d, tmax, skip_id);
+  while (!trav_done(tr)) {
+    if (trav_at_inner(tr)) trav_inner<Stack, STATS>(tr, st, sc, cnt);
+    else trav_leaf<Stack, STATS>(tr, st, sc, cnt);
   }
+  hit = tr.hit;
   return hit.id != kNoPrim;
 }
 

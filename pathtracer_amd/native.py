@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptk.so")
+# PTK_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("PTK_LIB") or os.path.join(_HERE, "libptk.so")
 
 
 class PtkError(RuntimeError):

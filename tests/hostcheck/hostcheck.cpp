@@ -19,8 +19,7 @@ struct HostStack {
   uint32_t data[kStackDepth];
   int sp = 0;
   int high_water = 0;
-  void reset() { sp = 0; }
-  bool empty() const { return sp == 0; }
+  void reset() { data[0] = (uint32_t)kTravDone; sp = 1; }
   void push(uint32_t v)
   {
     if (sp < kStackDepth) data[sp++] = v;
@@ -104,11 +103,10 @@ void hc_render(void* h, const ptk_camera* camera, const ptk_flags* flags, const 
       for (int x = 0; x < cam.width; x++) {
         HostStack st;
         Counters cnt = {0, 0, 0, 0, 0};
-        v3 sum = V3(0.f, 0.f, 0.f);
-        for (int s = 0; s < p->samples; s++) {
-          uint32_t sample = (uint32_t)(p->sample_first + s * p->sample_stride);
-          sum += trace_path<HostStack, true>(sc, cam, fl, p->max_bounce, x, y, sample, p->seed, st, cnt);
-        }
+        PathParams pp;
+        pp.px = x; pp.py = y; pp.samples = p->samples; pp.max_bounce = p->max_bounce;
+        pp.sample_first = p->sample_first; pp.sample_stride = p->sample_stride; pp.seed = p->seed;
+        v3 sum = render_pixel<HostStack, true>(sc, cam, fl, pp, st, cnt);
         float* a = accum + 4 * ((size_t)y * cam.width + x);
         a[0] += sum.x; a[1] += sum.y; a[2] += sum.z; a[3] += (float)p->samples;
         loc[0] += cnt.camera_rays; loc[1] += cnt.segments; loc[2] += cnt.queries; loc[3] += cnt.box_tests; loc[4] += cnt.prim_tests;

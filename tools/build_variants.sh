@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds tuning variants of libptk.so.  Each argument is name=FLAGS, e.g.
+#   tools/build_variants.sh "base=" "w4=-DPTK_MIN_WAVES=4"
+set -e
+cd "$(dirname "$0")/../pathtracer_amd/csrc"
+mkdir -p ../variants
+for v in "$@"; do
+  NAME=${v%%=*}; FLAGS=${v#*=}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $FLAGS \
+    -o ../variants/libptk_${NAME}.so ptk_kernels.hip ptk_build.cpp &
+done
+wait
+ls ../variants

@@ -1,0 +1,16 @@
+#!/bin/bash
+# On the GPU box: run bench.py once per library variant; one JSON line per variant in gpurun_out/sweep_<tag>.jsonl
+TAG=${1:-sweep}; shift
+ARGS="${@:---spp 64 --steps 3 --warmup 1 --no-cpu}"
+cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/sweep_$TAG.jsonl
+: > $OUT
+for lib in pathtracer_amd/variants/*.so; do
+  PTK_LIB=$PWD/$lib timeout -k 10 300 python3 bench.py $ARGS > gpurun_out/_sweep_one.json 2> gpurun_out/_sweep_one.err || { echo "FAILED $lib"; tail -3 gpurun_out/_sweep_one.err; exit 1; }
+  python3 - "$lib" <<'PY' >> $OUT
+import json,sys
+d=json.loads(open('gpurun_out/_sweep_one.json').read().strip().splitlines()[-1])
+print(json.dumps({"lib":sys.argv[1].split('/')[-1],"Mrays/s":round(d["value"],1),"ms_per_frame":round(d["ms_per_frame"],2),"kernel_ms":round(d["roofline"]["kernel_ms_avg"],2)}))
+PY
+done
+cat $OUT

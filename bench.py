@@ -8,8 +8,8 @@ the path kernel, with the scene already resident in HBM.  A ray is one closest-h
 (Scene::find_intersection, src/scene.cpp:19): a path segment or a shadow ray that is actually traced; the
 count comes from the kernel's own counters.  With N > 1 (one process per GPU, launched by
 torch.distributed.run) every GPU renders `spp` samples of the frame with interleaved global sample indices
-(weak scaling: the frame gets N x spp samples) and the accumulation buffers are summed onto rank 0 with one
-RCCL reduce per frame, inside the timed region.
+(weak scaling: the frame gets N x spp samples; --split tile shares one frame's rows instead) and the
+accumulation buffers are summed onto rank 0 with one RCCL reduce per frame, inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -72,7 +72,7 @@ def cpu_baseline(sd, spp_budget_s=12.0):
 def main():
     import torch
     import torch.distributed as dist
-    from pathtracer_amd import native
+    from pathtracer_amd import native, parallel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,17 +98,16 @@ def main():
     torch.cuda.synchronize()
     ctx.bind_accum(accum.data_ptr())
 
+    plan = parallel.frame_plan(ARGS.split, rank, world, ARGS.spp, ARGS.height, batch=ARGS.batch)
+
     def frame(step):
         accum.zero_()
         torch.cuda.synchronize()  # the kernel runs on the library's own stream
-        done = 0
-        while done < ARGS.spp:
-            n = min(ARGS.batch, ARGS.spp - done) if ARGS.batch > 0 else ARGS.spp
-            ctx.render(n, ARGS.bounces, seed=ARGS.seed + step, sample_first=rank + done * world, sample_stride=world)
-            done += n
+        for c in plan:
+            ctx.render(c.samples, ARGS.bounces, seed=ARGS.seed + step, sample_first=c.sample_first,
+                       sample_stride=c.sample_stride, row_begin=c.row_begin, row_end=c.row_end)
         ctx.synchronize()
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the frame's one exchange step
+        parallel.reduce_frame(accum, world)  # RCCL over xGMI: the frame's one exchange step
 
     for w in range(ARGS.warmup):
         frame(-1 - w)
@@ -164,11 +163,11 @@ def main():
         out = {
             "metric": "Mrays/s", "value": queries / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": ARGS.steps, "warmup": ARGS.warmup, "ms_per_step": elapsed / ARGS.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if ARGS.split == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ARGS.workload}: {WORKLOADS[ARGS.workload]}; {ARGS.width}x{ARGS.height}, "
                                    f"{ARGS.spp} spp per GPU, {ARGS.bounces} bounces",
                        "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"],
-                       "split": "spp (interleaved global sample indices), one RCCL reduce per frame" if world > 1 else "none",
+                       "split": (f"{ARGS.split} split, one RCCL reduce per frame" if world > 1 else "none"),
                        "launches_per_frame": st["launches"] // max(1, ARGS.steps)},
             "ms_per_frame": elapsed / ARGS.steps * 1e3,
             "segments_per_s": segments / elapsed, "paths_per_s": camera_rays / elapsed,
@@ -202,6 +201,8 @@ if __name__ == "__main__":
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="samples per launch (0 = the whole frame in one launch)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--split", default="spp", choices=["spp", "tile"],
+                    help="how N > 1 GPUs share a frame: interleaved sample indices or interleaved row bands")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ARGS = ap.parse_args()
     main()

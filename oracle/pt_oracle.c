@@ -706,13 +706,15 @@ static u8x3 image_pixel(const image_t* im, int x, int y)
   p.r = im->data[i]; p.g = im->data[i + 1]; p.b = im->data[i + 2];
   return p;
 }
-/* glm::mix(u8vec3, u8vec3, double): evaluated in double, converted back to u8 (truncation) */
+/* glm::mix(u8vec3, u8vec3, double): evaluated in double, converted back to u8 (truncation).  For a weight
+ * outside [0,1] (texture coordinates below 0 give a negative fraction) the blend can leave 0..255; the
+ * reference's x86-64 build then converts through a 32-bit integer and keeps the low byte. */
 static u8x3 mix_u8(u8x3 a, u8x3 b, double t)
 {
   u8x3 r;
-  r.r = (uint8_t)((double)a.r * (1.0 - t) + (double)b.r * t);
-  r.g = (uint8_t)((double)a.g * (1.0 - t) + (double)b.g * t);
-  r.b = (uint8_t)((double)a.b * (1.0 - t) + (double)b.b * t);
+  r.r = (uint8_t)(int32_t)((double)a.r * (1.0 - t) + (double)b.r * t);
+  r.g = (uint8_t)(int32_t)((double)a.g * (1.0 - t) + (double)b.g * t);
+  r.b = (uint8_t)(int32_t)((double)a.b * (1.0 - t) + (double)b.b * t);
   return r;
 }
 /* double -> int as the reference's x86-64 build does it (cvttsd2si): out of range and NaN give INT_MIN */

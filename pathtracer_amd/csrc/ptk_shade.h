@@ -110,13 +110,14 @@ PTK_HD Texel texel(const SceneView& sc, const TextureRec& t, int x, int y)
   return p;
 }
 
-// glm::mix on u8vec3 converts the blended value back to uint8 (truncation) at every lerp, src/image.cpp:78
+// glm::mix on u8vec3 converts the blended value back to uint8 (truncation) at every lerp, src/image.cpp:78;
+// out-of-range blends (negative fractions from texture coordinates below 0) keep their low byte
 PTK_HD Texel mix_u8(Texel a, Texel b, float t)
 {
   Texel r;
-  r.r = (int)((float)a.r * (1.0f - t) + (float)b.r * t);
-  r.g = (int)((float)a.g * (1.0f - t) + (float)b.g * t);
-  r.b = (int)((float)a.b * (1.0f - t) + (float)b.b * t);
+  r.r = ((int)((float)a.r * (1.0f - t) + (float)b.r * t)) & 255;
+  r.g = ((int)((float)a.g * (1.0f - t) + (float)b.g * t)) & 255;
+  r.b = ((int)((float)a.b * (1.0f - t) + (float)b.b * t)) & 255;
   return r;
 }
 

@@ -1,0 +1,70 @@
+"""Splitting one frame over several GPUs (one process per GPU) and putting it back together.
+
+Every (pixel, sample) path is independent (the reference's only parallel loop is over image rows,
+src/renderer.cpp:31-32), so a frame shards without any exchange while rendering; the one exchange step is the
+sum of the accumulation buffers at the end of the frame, which maps onto a single reduce (RCCL over xGMI when
+the process group's backend is "nccl").
+
+Two ways to shard, both with GLOBAL sample indices so that the union over ranks is exactly the sample set a
+single GPU would render:
+
+  "spp"   rank r renders sample indices r, r + world, r + 2*world, ... of every pixel;
+  "tile"  rank r renders all samples of the 16-row bands b with b % world == r (interleaved for balance).
+
+The accumulation buffer holds (sum r, sum g, sum b, sample count) per pixel, so a SUM reduce merges either
+kind of shard: disjoint bands add zeros, interleaved samples add partial sums and counts.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+BAND_ROWS = 16
+
+
+@dataclass
+class RenderCall:
+    samples: int
+    sample_first: int
+    sample_stride: int
+    row_begin: int
+    row_end: int
+
+
+def frame_plan(split: str, rank: int, world: int, samples_per_rank: int, height: int, sample_base: int = 0,
+               batch: int = 0) -> List[RenderCall]:
+    """The ptk_render calls rank `rank` makes for one frame.
+
+    spp split: each rank renders `samples_per_rank` samples (the frame gets world x samples_per_rank).
+    tile split: each rank renders `samples_per_rank` samples of its own bands (the frame gets samples_per_rank).
+    `batch` > 0 cuts the samples into launches of at most that many (Renderer::render called per batch,
+    src/main.cpp:242-252)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if split not in ("spp", "tile"):
+        raise ValueError("split must be 'spp' or 'tile'")
+    chunks = []
+    done = 0
+    while done < samples_per_rank:
+        n = min(batch, samples_per_rank - done) if batch > 0 else samples_per_rank
+        chunks.append((done, n))
+        done += n
+    calls: List[RenderCall] = []
+    if split == "spp":
+        for done, n in chunks:
+            calls.append(RenderCall(n, sample_base + rank + done * world, world, 0, height))
+    else:
+        n_bands = (height + BAND_ROWS - 1) // BAND_ROWS
+        for b in range(rank, n_bands, world):
+            for done, n in chunks:
+                calls.append(RenderCall(n, sample_base + done, 1, b * BAND_ROWS, min(height, (b + 1) * BAND_ROWS)))
+    return calls
+
+
+def reduce_frame(accum, world: int, dst: int = 0):
+    """Sum the ranks' accumulation buffers onto rank `dst` (a torch tensor of shape (H, W, 4)).
+    One collective per frame.  Needs an initialised torch.distributed process group when world > 1."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+    return accum

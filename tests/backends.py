@@ -90,6 +90,10 @@ def scene(name: str):
         return scenes.glass_scene(3, 48, 48)
     if name == "envmap":  # textured floor, environment map, depth of field, mesh
         return scenes.cornell_with_mesh(3, 64, 36, envmap=scenes.procedural_envmap(512, 256))
+    if name == "tiled":  # texture coordinates outside [0,1]: invalid taps and negative blend fractions
+        s = scenes.cornell_box(48, 48, aperture=0.0, focus_distance=0.0)
+        s.tri_uv = s.tri_uv * 3.0 - 1.0
+        return s
     if name == "sky":  # no background colour -> sky gradient; fuzzy specular + microfacet + sphere light
         s = scenes.cornell_box(48, 48, aperture=0.0, focus_distance=0.0)
         s.background_color = (-1.0, -1.0, -1.0)

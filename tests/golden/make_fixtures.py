@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Creates the data fixtures under tests/golden/ from files the reference repository holds.
+
+Run once in a container where /root/reference exists; the outputs are committed.  Every output is DATA
+(an image the reference renderer produced, or an input texture it ships), not source text.
+
+  reference_render_top200.png  rows 0..199 of doc/results/render_d94b533_1024_3_25-11-2024_202142.png, the
+                               reference's own 500x500 / 1024 spp / 3 bounce render of
+                               assets/cornell_box/cornell_box.json (box + glass bunny + two spheres + env map)
+  uv-test.png                  assets/textures/uv-test.png (the floor's map_Kd), unchanged
+  prater_448x224.png           assets/textures/prater.jpg (the environment map) box-filtered 8x down
+"""
+import os
+import shutil
+
+import numpy as np
+from PIL import Image
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+im = Image.open(os.path.join(REF, "doc/results/render_d94b533_1024_3_25-11-2024_202142.png")).convert("RGB")
+im.crop((0, 0, 500, 200)).save(os.path.join(OUT, "reference_render_top200.png"), optimize=True)
+shutil.copyfile(os.path.join(REF, "assets/textures/uv-test.png"), os.path.join(OUT, "uv-test.png"))
+env = np.asarray(Image.open(os.path.join(REF, "assets/textures/prater.jpg")).convert("RGB"), np.float64)
+h, w, _ = env.shape
+small = env.reshape(h // 8, 8, w // 8, 8, 3).mean(axis=(1, 3))
+Image.fromarray(np.clip(small + 0.5, 0, 255).astype(np.uint8)).save(os.path.join(OUT, "prater_448x224.png"), optimize=True)
+print("fixtures written to", OUT)

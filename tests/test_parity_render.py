@@ -26,6 +26,7 @@ CASES = [
     ("glass", 24, 8),            # dielectric mesh, 8 bounces
     ("envmap", 24, 3),           # environment map + textured floor + depth of field
     ("sky", 24, 4),              # sky gradient, fuzzy specular, microfacet, sphere light
+    ("tiled", 16, 3),            # floor texture coordinates in [-1, 2]
 ]
 
 

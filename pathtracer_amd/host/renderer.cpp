@@ -1,0 +1,120 @@
+#include "renderer.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <ctime>
+#include <iomanip>
+#include <iostream>
+
+#include "../../include/ptk.h"
+#include "config.h"
+#include "image.h"
+
+static void check(ptk_ctx* ctx, int rc, const char* what)
+{
+  if (rc != PTK_OK) {
+    std::cerr << what << ": " << ptk_last_error(ctx) << std::endl;
+    std::exit(1);
+  }
+}
+
+Renderer::Renderer(Camera* camera, Scene* scene, int max_bounce) : m_scene(scene), m_camera(camera), m_max_bounce(max_bounce)
+{
+  ptk_ctx* ctx = m_scene->context();
+  if (!ctx) {
+    std::cerr << "Renderer: call Scene::compute_bvh() before constructing a Renderer" << std::endl;
+    std::exit(1);
+  }
+  ptk_camera c{};
+  c.width = m_camera->width();
+  c.height = m_camera->height();
+  pt::dvec3 p = m_camera->position(), f = m_camera->direction(), r = m_camera->right(), u = m_camera->up();
+  c.position[0] = p.x; c.position[1] = p.y; c.position[2] = p.z;
+  c.forward[0] = f.x; c.forward[1] = f.y; c.forward[2] = f.z;
+  c.right[0] = r.x; c.right[1] = r.y; c.right[2] = r.z;
+  c.up[0] = u.x; c.up[1] = u.y; c.up[2] = u.z;
+  c.fov = m_camera->fov_radians();
+  c.aperture = m_camera->aperture();
+  c.focus_distance = m_camera->focus_distance();
+  check(ctx, ptk_set_camera(ctx, &c), "ptk_set_camera");  // allocates and clears the W*H buffer (src/renderer.cpp:19-25)
+  ptk_flags fl{PT_DEBUG_NORMAL, PT_RUSSIAN_ROULETTE, PT_DIRECT_LIGHT_SAMPLING, PT_INDIRECT_LIGHT_SAMPLING,
+               PT_IMPORTANCE_SAMPLE, PT_CHECK_HEMISPHERE};
+  check(ctx, ptk_set_flags(ctx, &fl), "ptk_set_flags");
+}
+
+// src/renderer.cpp:27-52
+void Renderer::render(int samples, bool print_progress)
+{
+  ptk_ctx* ctx = m_scene->context();
+  ptk_render_params p{};
+  p.samples = samples;
+  p.max_bounce = m_max_bounce;
+  p.seed = m_seed;
+  p.sample_first = total_samples;
+  p.sample_stride = 1;
+  if (print_progress) {
+    // the reference prints one line per image row; rows finish together here, so progress is per band
+    const int band = 64;
+    for (int y = 0; y < m_camera->height(); y += band) {
+      printf("Progress: %.2f%%\n", (double(y) / double(m_camera->height())) * 100.0);
+      p.row_begin = y;
+      p.row_end = std::min(m_camera->height(), y + band);
+      check(ctx, ptk_render(ctx, &p), "ptk_render");
+      check(ctx, ptk_synchronize(ctx), "ptk_synchronize");
+    }
+  } else {
+    check(ctx, ptk_render(ctx, &p), "ptk_render");
+    check(ctx, ptk_synchronize(ctx), "ptk_synchronize");
+  }
+  total_samples += samples;
+}
+
+std::vector<float> Renderer::read_buffer()
+{
+  ptk_ctx* ctx = m_scene->context();
+  std::vector<float> rgb((size_t)m_camera->width() * (size_t)m_camera->height() * 3);
+  check(ctx, ptk_read_accum(ctx, rgb.data(), nullptr), "ptk_read_accum");
+  return rgb;
+}
+
+// Narkowicz 2015, "ACES Filmic Tone Mapping Curve" (src/renderer.cpp:174-178)
+static double aces_tone_map(double x)
+{
+  const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14;
+  return (x * (a * x + b)) / (x * (c * x + d) + e);
+}
+
+// src/renderer.cpp:10: clamp to [0,1], scale by 255, truncate
+static uint8_t map_pixel(double color)
+{
+  double c = color < 0.0 ? 0.0 : (color > 1.0 ? 1.0 : color);
+  if (!(color == color)) c = 0.0;
+  return static_cast<uint8_t>(c * 255.0);
+}
+
+// src/renderer.cpp:180-201
+void Renderer::save_image(const std::filesystem::path& path)
+{
+  std::vector<float> rgb = read_buffer();
+  Image output(m_camera->width(), m_camera->height(), 3);
+  for (int y = 0; y < m_camera->height(); y++) {
+    for (int x = 0; x < m_camera->width(); x++) {
+      unsigned char pixel[3];
+      for (int k = 0; k < 3; k++) {
+        double color = rgb[((size_t)y * m_camera->width() + x) * 3 + k];
+        color = aces_tone_map(color);
+        color = std::pow(color, 1.0 / 2.2);  // gamma_correction, src/util.h:131-134
+        pixel[k] = map_pixel(color);
+      }
+      output.set_pixel(x, y, pixel);
+    }
+  }
+  output.write(path);
+
+  auto now = std::chrono::system_clock::now();
+  std::time_t current_time = std::chrono::system_clock::to_time_t(now);
+  std::cout << "[" << std::put_time(std::localtime(&current_time), "%Y-%m-%d %H:%M:%S") << "] Save image to " << path
+            << std::endl;
+}
+

@@ -286,3 +286,74 @@ def glass_scene(level: int = 5, width: int = 500, height: int = 500) -> SceneDat
                           mesh_material=Material(type=DIELECTRIC, albedo=(1.0, 1.0, 1.0), roughness=0.5, metallic=0.5))
     add_json_spheres(s)
     return s
+
+
+# ---------------------------------------------------------------------------------------------
+# Asset files for the command-line driver (`pt`): the same Cornell box as cornell_box(), written as
+# OBJ / MTL / PNG / JSON text the way the reference's asset directory is laid out.
+_CORNELL_QUADS = [
+    # name, material, vertices (4), texture coordinates (4), normal
+    ("Back_Roof", "White", [(5, 10, 5), (-5, 10, 5), (-5, 10, -5), (5, 10, -5)],
+     [(0.625, 0.5), (0.625, 0.75), (0.875, 0.75), (0.875, 0.5)], (0, -1, 0)),
+    ("Back_Wall", "White", [(-5, 0, -5), (5, 0, -5), (5, 10, -5), (-5, 10, -5)],
+     [(0.375, 0.0), (0.375, 0.25), (0.625, 0.25), (0.625, 0.0)], (0, 0, 1)),
+    ("Left_Wall", "Red", [(-5, 0, 5), (-5, 0, -5), (-5, 10, -5), (-5, 10, 5)],
+     [(0.375, 0.75), (0.375, 1.0), (0.625, 1.0), (0.625, 0.75)], (1, 0, 0)),
+    ("Right_Wall", "Green", [(5, 0, -5), (5, 0, 5), (5, 10, 5), (5, 10, -5)],
+     [(0.375, 0.25), (0.375, 0.5), (0.625, 0.5), (0.625, 0.25)], (-1, 0, 0)),
+    ("Light_Plane", "Material", [(-0.947293, 9.862494, -0.947293), (0.947293, 9.862494, -0.947293),
+                                 (0.947293, 9.862494, 0.947293), (-0.947293, 9.862494, 0.947293)],
+     [(0, 0), (1, 0), (1, 1), (0, 1)], (0, -1, 0)),
+    ("Floor", "Textured", [(5, 0, -5), (-5, 0, -5), (-5, 0, 5), (5, 0, 5)],
+     [(0.9999, 0.0001), (0.9999, 0.9999), (0.0001, 0.9999), (0.0001, 0.0001)], (0, 1, 0)),
+]
+
+
+def write_cornell_assets(directory, width=64, height=64, texture: Optional[np.ndarray] = None, spheres: bool = False,
+                         aperture: float = 0.5, focus_distance: float = 24.0) -> str:
+    """Writes cornell_box.obj / .mtl / floor texture / config JSON into `directory`; returns the JSON path.
+    The geometry, materials and camera equal cornell_box(width, height, texture=...)."""
+    import json
+    import os
+    from PIL import Image as PILImage
+    os.makedirs(directory, exist_ok=True)
+    tex = texture if texture is not None else procedural_texture()
+    PILImage.fromarray(np.flipud(tex)).save(os.path.join(directory, "floor.png"))  # file rows are top-down
+    with open(os.path.join(directory, "cornell_box.mtl"), "w") as f:
+        def mtl(name, kd, ke=(0, 0, 0), extra=""):
+            f.write(f"newmtl {name}\nNs 225.000000\nKa 1.000000 1.000000 1.000000\nKd {kd[0]:.6f} {kd[1]:.6f} {kd[2]:.6f}\n"
+                    f"Ks 0.500000 0.500000 0.500000\nKe {ke[0]:.6f} {ke[1]:.6f} {ke[2]:.6f}\nNi 1.450000\nd 1.000000\nillum 2\n{extra}\n")
+        mtl("Green", (0, 1, 0))
+        mtl("Material", (0.8, 0.8, 0.8), (10, 10, 10))
+        mtl("Red", (1, 0, 0))
+        mtl("Textured", (1, 1, 1), extra="map_Kd floor.png\n")
+        mtl("White", (0.8, 0.8, 0.8))
+    with open(os.path.join(directory, "cornell_box.obj"), "w") as f:
+        f.write("# generated\nmtllib cornell_box.mtl\n")
+        nv = nt = nn = 0
+        for name, mat, verts, uvs, normal in _CORNELL_QUADS:
+            f.write(f"o {name}\n")
+            for v in verts:
+                f.write(f"v {v[0]:.6f} {v[1]:.6f} {v[2]:.6f}\n")
+            for t in uvs:
+                f.write(f"vt {t[0]:.6f} {t[1]:.6f}\n")
+            f.write(f"vn {normal[0]:.4f} {normal[1]:.4f} {normal[2]:.4f}\nusemtl {mat}\ns off\n")
+            f.write("f " + " ".join(f"{nv + k + 1}/{nt + k + 1}/{nn + 1}" for k in range(4)) + "\n")
+            nv += 4; nt += 4; nn += 1
+    cfg = {
+        "image_width": width, "image_height": height, "camera_aperture": aperture,
+        "camera_focus_distance": focus_distance, "camera_position": {"x": 0, "y": 5, "z": 24},
+        "camera_target": {"x": 0, "y": 5, "z": 0}, "camera_fov": 14.5,
+        "models": [os.path.join(directory, "cornell_box.obj")],
+        "background_color": {"x": 0, "y": 0, "z": 0},
+    }
+    if spheres:
+        cfg["spheres"] = [
+            {"center": {"x": 3, "y": 1.5, "z": 2.5}, "radius": 1.5, "type": "TRANSMISSIVE"},
+            {"center": {"x": -3, "y": 1.5, "z": -2.5}, "radius": 1.5, "type": "SPECULAR", "roughness": 0.0},
+            {"hidden": True, "center": {"x": 0, "y": 8, "z": 0}, "radius": 1.5, "emissive": {"x": 2, "y": 2, "z": 2}},
+        ]
+    path = os.path.join(directory, "cornell_box.json")
+    with open(path, "w") as f:
+        json.dump(cfg, f, indent=1)
+    return path

@@ -1,0 +1,174 @@
+"""The C++ host side (pathtracer_amd/host): image codecs, OBJ/MTL loading, and -- on the GPU -- the `pt`
+command-line driver end to end (JSON config -> Scene / Camera / Renderer -> PNG), compared with the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from pathtracer_amd import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST_LIB = os.path.join(ROOT, "pathtracer_amd", "libpt_host.so")
+PT = os.path.join(ROOT, "pathtracer_amd", "pt")
+
+
+@pytest.fixture(scope="module")
+def host():
+    assert os.path.exists(HOST_LIB), "build the host library first (__graft_entry__.build())"
+    L = C.CDLL(HOST_LIB)
+    L.pt_host_image_load.restype = C.c_void_p
+    L.pt_host_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pt_host_free.argtypes = [C.c_void_p]
+    L.pt_host_image_write.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+    L.pt_host_load_obj.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 7 + [C.POINTER(C.c_int)]
+    return L
+
+
+def _load(host, path):
+    w, h = C.c_int(), C.c_int()
+    p = host.pt_host_image_load(str(path).encode(), C.byref(w), C.byref(h))
+    if not p:
+        return None
+    a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+    host.pt_host_free(p)
+    return a
+
+
+def test_png_decode_variants(host, tmp_path):
+    rng = np.random.RandomState(1)
+    rgb = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    cases = {
+        "rgb": Image.fromarray(rgb),
+        "rgba": Image.fromarray(np.dstack([rgb, rng.randint(0, 256, (37, 53)).astype(np.uint8)]), "RGBA"),
+        "grey": Image.fromarray(rgb[..., 0], "L"),
+        "palette": Image.fromarray(rgb).quantize(64),
+        "grey16": Image.fromarray((rgb[..., 0].astype(np.uint16) * 257), "I;16"),
+        "bilevel": Image.fromarray(rgb[..., 0] > 127),
+    }
+    for name, im in cases.items():
+        p = tmp_path / f"{name}.png"
+        im.save(p)
+        got = _load(host, p)
+        assert got is not None, name
+        expect = np.asarray(Image.open(p).convert("RGB"))
+        if name == "grey16":  # 16-bit samples keep their high byte (Pillow's conversion saturates instead)
+            expect = np.repeat(rgb[..., :1], 3, axis=2)
+        # rows come back bottom-up, as the reference's loader flips them (src/image.cpp:29)
+        assert np.array_equal(got, np.flipud(expect)), name
+    assert _load(host, tmp_path / "missing.png") is None
+    (tmp_path / "junk.png").write_bytes(b"not a png at all")
+    assert _load(host, tmp_path / "junk.png") is None
+    inter = tmp_path / "interlaced.png"
+    # Pillow cannot write Adam7; flip the header's interlace byte (and leave the CRC: it is not checked)
+    raw = bytearray((tmp_path / "rgb.png").read_bytes())
+    raw[28] = 1
+    inter.write_bytes(bytes(raw))
+    assert _load(host, inter) is None
+
+
+def test_png_encode_round_trip(host, tmp_path):
+    rng = np.random.RandomState(2)
+    rgb = rng.randint(0, 256, (29, 41, 3)).astype(np.uint8)
+    p = tmp_path / "out.png"
+    assert host.pt_host_image_write(str(p).encode(), rgb.ctypes.data, 41, 29) == 1
+    assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), rgb)  # row 0 of the buffer = top of the file
+
+
+def test_jpeg_baseline_decode(host, tmp_path):
+    ys, xs = np.mgrid[0:96, 0:160]
+    smooth = np.stack([128 + 100 * np.sin(xs / 23.0), 128 + 90 * np.cos(ys / 17.0), 60 + xs * 0.8], -1)
+    img = Image.fromarray(np.clip(smooth, 0, 255).astype(np.uint8))
+    for name, kw in {"444": dict(subsampling=0), "420": dict(subsampling=2), "422": dict(subsampling=1),
+                     "restart": dict(subsampling=2, restart_marker_blocks=3)}.items():
+        p = tmp_path / f"{name}.jpg"
+        try:
+            img.save(p, quality=92, **kw)
+        except TypeError:
+            continue
+        got = _load(host, p)
+        assert got is not None, name
+        expect = np.flipud(np.asarray(Image.open(p).convert("RGB"))).astype(int)
+        d = np.abs(got.astype(int) - expect)
+        assert d.mean() < 1.5 and d.max() <= 12, (name, d.mean(), d.max())  # IDCT / chroma upsampling latitude
+    grey = tmp_path / "grey.jpg"
+    img.convert("L").save(grey, quality=90)
+    got = _load(host, grey)
+    assert got is not None and np.abs(got[..., 0].astype(int) - np.flipud(np.asarray(Image.open(grey))).astype(int)).max() <= 2
+    prog = tmp_path / "prog.jpg"
+    img.save(prog, quality=90, progressive=True)
+    assert _load(host, prog) is None  # reported as unsupported, not mis-decoded
+
+
+def test_obj_loader_matches_the_procedural_cornell_box(host, tmp_path):
+    """Quads are split like the reference's OBJ reader, numbers pass through float, material attributes follow
+    the illum / Kd / Ke mapping of src/scene.cpp:127-152, and emissive triangles become lights."""
+    cfg = scenes.write_cornell_assets(str(tmp_path), 32, 32)
+    sd = scenes.cornell_box(32, 32)
+    n = 64
+    pos, nrm, uv = np.zeros((n, 9)), np.zeros((n, 9)), np.zeros((n, 6))
+    mtype, tex = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    alb, emi = np.zeros((n, 3)), np.zeros((n, 3))
+    nl = C.c_int()
+    k = host.pt_host_load_obj(os.path.join(str(tmp_path), "cornell_box.obj").encode(), n, pos.ctypes.data, nrm.ctypes.data,
+                              uv.ctypes.data, mtype.ctypes.data, alb.ctypes.data, emi.ctypes.data, tex.ctypes.data, C.byref(nl))
+    assert k == 12 and nl.value == 2
+    assert np.array_equal(pos[:12].reshape(12, 3, 3), sd.tri_pos)
+    assert np.array_equal(nrm[:12].reshape(12, 3, 3), sd.tri_nrm)
+    assert np.array_equal(uv[:12].reshape(12, 3, 2), sd.tri_uv)
+    for i in range(12):
+        m = sd.materials[sd.tri_mat[i]]
+        assert mtype[i] == m.type and np.allclose(alb[i], m.albedo) and np.allclose(emi[i], m.emission)
+        assert tex[i] == (1 if m.texture >= 0 else 0)
+    assert os.path.exists(cfg)
+
+
+def test_obj_loader_polygons_and_relative_indices(host, tmp_path):
+    (tmp_path / "p.obj").write_text(
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 1.5 0\nvn 0 0 1\n"
+        "f -5//1 -4//1 -3//1 -2//1 -1//1\n"   # pentagon, relative indices -> fan of 3 triangles
+        "f 1 2 3\n"                            # no normals, no uvs
+        "v 3 0 0\nv 2 0 0\nv 2 0.1 0\nv 3 5 0\n"
+        "f 6 7 8 9\n")                         # diagonal 6-8 shorter than 7-9 -> [0,1,2],[0,2,3]
+    n = 16
+    pos, nrm, uv = np.zeros((n, 9)), np.zeros((n, 9)), np.zeros((n, 6))
+    mtype, tex = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    alb, emi = np.zeros((n, 3)), np.zeros((n, 3))
+    k = host.pt_host_load_obj(str(tmp_path / "p.obj").encode(), n, pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data,
+                              mtype.ctypes.data, alb.ctypes.data, emi.ctypes.data, tex.ctypes.data, None)
+    assert k == 6
+    P = pos[:6].reshape(6, 3, 3)
+    assert np.allclose(P[0], [[0, 0, 0], [1, 0, 0], [1, 1, 0]]) and np.allclose(P[2], [[0, 0, 0], [0, 1, 0], [0.5, 1.5, 0]])
+    assert np.allclose(nrm[0].reshape(3, 3), [[0, 0, 1]] * 3) and not nrm[3].any()
+    assert np.allclose(P[4], [[3, 0, 0], [2, 0, 0], [2, 0.1, 0]]) and np.allclose(P[5], [[3, 0, 0], [2, 0.1, 0], [3, 5, 0]])
+    assert (mtype[:6] == scenes.DIFFUSE).all() and np.allclose(alb[:6], 0.5)  # no mtllib: the default material
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_spheres", [False, True])
+def test_pt_command_line_matches_oracle(tmp_path, with_spheres):
+    """pt <config> <out> <samples> <bounces> <batch>: argv order, JSON keys and the batch loop of
+    src/main.cpp:172-270; the PNG must match the oracle's tone-mapped render of the same scene and seed."""
+    from oracle import orc
+    cfg = scenes.write_cornell_assets(str(tmp_path), 64, 64, spheres=with_spheres)
+    out = tmp_path / "result.png"
+    env = dict(os.environ, PT_SEED="5")
+    r = subprocess.run([PT, cfg, str(out), "32", "4", "16"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "32/32 samples per pixel" in r.stdout and "Render time:" in r.stdout and "Primitive Count: %d" % (14 if with_spheres else 12) in r.stdout
+    assert (tmp_path / "latest.png").exists()
+    got = np.asarray(Image.open(out).convert("RGB")).astype(int)
+    sd = scenes.cornell_box(64, 64)
+    if with_spheres:
+        scenes.add_json_spheres(sd)
+    o = orc.OracleScene(sd)
+    ref, _ = o.render(32, 4, seed=5)
+    ref8 = orc.tonemap_u8(ref).astype(int)
+    d = np.abs(got - ref8)
+    print("mean abs diff", d.mean())
+    assert d.mean() < 2.0
+    # usage message and a missing config are errors, as in the reference
+    assert subprocess.run([PT], capture_output=True).returncode == 1
+    assert subprocess.run([PT, str(tmp_path / "nope.json"), str(out)], capture_output=True).returncode == 1

@@ -8,7 +8,9 @@
 // (and its L2) render adjacent tiles.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -20,8 +22,12 @@
 
 namespace ptk {
 
-constexpr int kBlock = 256;
-constexpr int kTile = 16;
+#ifndef PTK_BLOCK_WAVES
+#define PTK_BLOCK_WAVES 1  // waves per workgroup: 4 = 16x16 pixel tiles, 1 = 8x8 pixel tiles
+#endif
+constexpr int kBlock = 64 * PTK_BLOCK_WAVES;
+constexpr int kTile = PTK_BLOCK_WAVES == 4 ? 16 : 8;
+static_assert(PTK_BLOCK_WAVES == 4 || PTK_BLOCK_WAVES == 1, "tiles are one wave or 2x2 waves");
 
 // Wave scheduling knobs of the render kernel (see its main loop).
 // Measured on the 81,920-triangle mesh scene (1024x1024, 64 spp, 3 bounces; Mrays/s): strict
@@ -35,6 +41,13 @@ constexpr int kTile = 16;
 #ifndef PTK_MIN_WAVES
 #define PTK_MIN_WAVES 4     // __launch_bounds__ waves per SIMD for the render kernel (3: 3.47k, 4: 3.79k, 5: 3.03k Mrays/s)
 #endif
+#ifndef PTK_CHUNK_ROUNDS
+#define PTK_CHUNK_ROUNDS 32       // split tiles into sample chunks until the grid is this many times the resident waves
+#endif
+#ifndef PTK_CHUNK_MIN_SAMPLES
+#define PTK_CHUNK_MIN_SAMPLES 16  // ... but never below this many samples per chunk
+#endif
+constexpr int kMaxChunks = 32;
 constexpr int kDescendMin = PTK_DESCEND_MIN;
 constexpr int kRefillMin = PTK_REFILL_MIN;
 
@@ -55,6 +68,7 @@ struct RenderArgs {
   int32_t sample_first, sample_stride;
   int32_t row_begin, row_end;
   int32_t tiles_x, n_tiles;
+  int32_t chunks;  // workgroups per tile; each takes every chunks-th sample
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin, so ids b and b+8 share an L2.  Give each
@@ -65,6 +79,16 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
   int q = n >> 3, r = n & 7;
   int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + k;
+}
+
+// Position v in the list 0, 8, 16, ..., 1, 9, 17, ..., 7, 15, ... of the rows below n -> that row.
+__device__ __forceinline__ int interleave_rows(int v, int n)
+{
+  int q = n >> 3, r = n & 7;
+  int cut = r * (q + 1);
+  if (v < cut) return (v % (q + 1)) * 8 + v / (q + 1);
+  v -= cut;
+  return (v % q) * 8 + r + v / q;
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -88,15 +112,21 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView sc, CameraView cam, FlagView fl, RenderArgs ra,
-                                                        f4* __restrict__ accum, unsigned long long* counters)
+                                                        f4* __restrict__ accum, f4* __restrict__ partial,
+                                                        unsigned long long* counters)
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   LdsStack st;
   st.base = lds_stack + threadIdx.x;
   st.sp = 0;
 
-  int tile = xcd_remap((int)blockIdx.x, ra.n_tiles);
+  // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
+  // tile, then the next tile of the same tile row; tile rows are dealt to the XCDs round-robin
+  // (row r -> XCD r % 8) so that every XCD sees the same mix of cheap and expensive image regions.
+  int virt = xcd_remap((int)blockIdx.x, ra.n_tiles * ra.chunks);
+  int tile = virt / ra.chunks, chunk = virt - tile * ra.chunks;
   int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
+  ty = interleave_rows(ty, ra.n_tiles / ra.tiles_x);
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
   int py = ra.row_begin + ty * kTile + (wave >> 1) * 8 + (lane >> 3);
@@ -104,8 +134,10 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   Counters cnt = {0, 0, 0, 0, 0};
   const bool in_image = px < cam.width && py < ra.row_end;
   PathParams pp;
-  pp.px = px; pp.py = py; pp.samples = ra.samples; pp.max_bounce = ra.max_bounce;
-  pp.sample_first = ra.sample_first; pp.sample_stride = ra.sample_stride; pp.seed = ra.seed;
+  pp.px = px; pp.py = py; pp.max_bounce = ra.max_bounce; pp.seed = ra.seed;
+  pp.samples = (ra.samples - chunk + ra.chunks - 1) / ra.chunks;  // chunk c takes samples c, c + chunks, ...
+  pp.sample_first = ra.sample_first + chunk * ra.sample_stride;
+  pp.sample_stride = ra.sample_stride * ra.chunks;
   PathState ps;
   path_init(ps, st, sc, cam, pp, in_image, cnt);
 
@@ -131,12 +163,35 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     }
   }
   if (in_image) {
-    size_t i = (size_t)py * (size_t)cam.width + (size_t)px;
-    f4 a = accum[i];
-    a.x += ps.sum.x; a.y += ps.sum.y; a.z += ps.sum.z; a.w += (float)ra.samples;
-    accum[i] = a;
+    if (ra.chunks == 1) {
+      size_t i = (size_t)py * (size_t)cam.width + (size_t)px;
+      f4 a = accum[i];
+      a.x += ps.sum.x; a.y += ps.sum.y; a.z += ps.sum.z; a.w += (float)pp.samples;
+      accum[i] = a;
+    } else {
+      size_t rows = (size_t)(ra.row_end - ra.row_begin);
+      size_t i = ((size_t)chunk * rows + (size_t)(py - ra.row_begin)) * (size_t)cam.width + (size_t)px;
+      f4 a;
+      a.x = ps.sum.x; a.y = ps.sum.y; a.z = ps.sum.z; a.w = (float)pp.samples;
+      partial[i] = a;
+    }
   }
   flush_counters(cnt, counters);
+}
+
+// accum[row_begin .. row_end) += partial[0] + partial[1] + ... in that order (one fixed summation
+// order, so a frame does not depend on which workgroup finished first).
+__global__ __launch_bounds__(256) void fold_partials_kernel(f4* __restrict__ accum, const f4* __restrict__ partial,
+                                                            size_t first, size_t count, int chunks)
+{
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  f4 a = accum[first + i];
+  for (int c = 0; c < chunks; c++) {
+    f4 p = partial[(size_t)c * count + i];
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+  }
+  accum[first + i] = a;
 }
 
 template <bool STATS>
@@ -193,6 +248,8 @@ struct ptk_ctx {
   f4* d_accum_own = nullptr;
   f4* d_accum = nullptr;  // own or bound
   size_t accum_pixels = 0;
+  f4* d_partial = nullptr;  // per-chunk partial sums of the frame being rendered
+  size_t partial_capacity = 0;  // in f4
   // counters and timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -267,6 +324,23 @@ static int upload(ptk_ctx* ctx, void** dst, const std::vector<T>& src)
   return PTK_OK;
 }
 
+// Workgroups per tile.  A frame whose tiles alone give the chip only a few rounds of workgroups
+// ends with most CUs idle while the slowest tiles finish; splitting every tile's samples over
+// several workgroups shortens that tail.  Each chunk keeps at least kMinChunkSamples samples so
+// that a lane still has work to refill with when its neighbours' paths end.
+static int pick_chunks(int n_tiles, int samples)
+{
+  constexpr int64_t kResidentWaves = 256 * 4 * PTK_MIN_WAVES;
+  constexpr int64_t kRounds = PTK_CHUNK_ROUNDS;
+  constexpr int kMinChunkSamples = PTK_CHUNK_MIN_SAMPLES;
+  int64_t waves = (int64_t)n_tiles * PTK_BLOCK_WAVES;
+  int64_t want = (kRounds * kResidentWaves + waves - 1) / waves;
+  int64_t cap = std::max(1, samples / kMinChunkSamples);
+  int64_t c = std::min<int64_t>(std::min(want, cap), kMaxChunks);
+  if (const char* e = getenv("PTK_CHUNKS")) { int v = atoi(e); if (v >= 1) c = std::min<int64_t>(v, std::min<int64_t>(samples, 64)); }
+  return (int)std::max<int64_t>(c, 1);
+}
+
 extern "C" {
 
 int ptk_create(int device, ptk_ctx** out)
@@ -301,6 +375,7 @@ int ptk_destroy(ptk_ctx* ctx)
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_scene(ctx);
   if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
+  if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -431,17 +506,40 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
   ra.tiles_x = (ctx->cam.width + kTile - 1) / kTile;
   int tiles_y = (ra.row_end - ra.row_begin + kTile - 1) / kTile;
   ra.n_tiles = ra.tiles_x * tiles_y;
+  ra.chunks = pick_chunks(ra.n_tiles, p->samples);
   PTK_HIP(hipSetDevice(ctx->device));
+  size_t band_pixels = (size_t)(ra.row_end - ra.row_begin) * (size_t)ctx->cam.width;
+  if (ra.chunks > 1) {
+    size_t need = band_pixels * (size_t)ra.chunks;
+    if (need > ctx->partial_capacity) {
+      PTK_HIP(hipStreamSynchronize(ctx->stream));  // an earlier frame may still be folding the old buffer
+      if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+      ctx->d_partial = nullptr;
+      ctx->partial_capacity = 0;
+      PTK_HIP(hipMalloc((void**)&ctx->d_partial, need * sizeof(f4)));
+      ctx->partial_capacity = need;
+    }
+  }
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc = begin_timed(ctx, ev);
   if (rc) return rc;
-  dim3 grid((unsigned)ra.n_tiles), block(kBlock);
+  dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
   if (p->collect_stats)
-    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum, ctx->d_counters);
+    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
+                       ctx->d_partial, ctx->d_counters);
   else
-    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum, ctx->d_counters);
+    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
+                       ctx->d_partial, ctx->d_counters);
   PTK_HIP(hipGetLastError());
-  return end_timed(ctx, ev);
+  rc = end_timed(ctx, ev);
+  if (rc) return rc;
+  if (ra.chunks > 1) {
+    size_t first = (size_t)ra.row_begin * (size_t)ctx->cam.width;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((band_pixels + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum,
+                       ctx->d_partial, first, band_pixels, ra.chunks);
+    PTK_HIP(hipGetLastError());
+  }
+  return PTK_OK;
 }
 
 int ptk_synchronize(ptk_ctx* ctx)

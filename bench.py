@@ -136,7 +136,7 @@ def main():
     ctx.reset_stats()
     accum.zero_()
     torch.cuda.synchronize()
-    ctx.render(max(1, min(4, ARGS.spp)), ARGS.bounces, seed=7, collect_stats=True)
+    ctx.render(max(1, min(ARGS.stats_spp, ARGS.spp)), ARGS.bounces, seed=7, collect_stats=True)
     si = ctx.stats()
     box_per_ray = si["box_tests"] / max(1, si["queries"])
     prim_per_ray = si["prim_tests"] / max(1, si["queries"])
@@ -201,6 +201,7 @@ if __name__ == "__main__":
     ap.add_argument("--bounces", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="samples per launch (0 = the whole frame in one launch)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--stats-spp", type=int, default=4, help="samples per pixel of the instrumented (test-counting) pass")
     ap.add_argument("--split", default="spp", choices=["spp", "tile"],
                     help="how N > 1 GPUs share a frame: interleaved sample indices or interleaved row bands")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -22,12 +22,8 @@
 
 namespace ptk {
 
-#ifndef PTK_BLOCK_WAVES
-#define PTK_BLOCK_WAVES 1  // waves per workgroup: 4 = 16x16 pixel tiles, 1 = 8x8 pixel tiles
-#endif
-constexpr int kBlock = 64 * PTK_BLOCK_WAVES;
-constexpr int kTile = PTK_BLOCK_WAVES == 4 ? 16 : 8;
-static_assert(PTK_BLOCK_WAVES == 4 || PTK_BLOCK_WAVES == 1, "tiles are one wave or 2x2 waves");
+constexpr int kBlock = 64;  // one wave per workgroup: a finished wave frees its slot at once
+constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 
 // Wave scheduling knobs of the render kernel (see its main loop).
 // Measured on the 81,920-triangle mesh scene (1024x1024, 64 spp, 3 bounces; Mrays/s): strict
@@ -48,6 +44,16 @@ static_assert(PTK_BLOCK_WAVES == 4 || PTK_BLOCK_WAVES == 1, "tiles are one wave 
 #define PTK_CHUNK_MIN_SAMPLES 16  // ... but never below this many samples per chunk
 #endif
 constexpr int kMaxChunks = 32;
+constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters of a PTK_PHASE_STATS build
+
+// A build with -DPTK_PHASE_STATS makes instrumented launches also count, per wave, how often each
+// phase of the render loop ran and how many lanes it ran for (printed by ptk_get_stats when the
+// environment has PTK_PHASE_STATS set).  A profiling aid only; normal builds compile it away.
+#ifdef PTK_PHASE_STATS
+#define PTK_PHASE(...) __VA_ARGS__
+#else
+#define PTK_PHASE(...)
+#endif
 constexpr int kDescendMin = PTK_DESCEND_MIN;
 constexpr int kRefillMin = PTK_REFILL_MIN;
 
@@ -60,6 +66,18 @@ struct LdsStack {
     if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // the builder keeps trees shallower than the stack
   }
   __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * kBlock]; }
+};
+
+// Per-pixel radiance sums of a tile, in LDS.  Two lanes can finish paths of the same pixel in the
+// same step, hence the atomic add (ds_add_f32).
+struct LdsAccum {
+  float* base;
+  __device__ __forceinline__ void add(uint32_t slot, v3 L)
+  {
+    __hip_atomic_fetch_add(base + slot, L.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(base + 64 + slot, L.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(base + 128 + slot, L.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 };
 
 struct RenderArgs {
@@ -116,6 +134,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
                                                         unsigned long long* counters)
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
   st.base = lds_stack + threadIdx.x;
   st.sp = 0;
@@ -127,31 +146,55 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   int tile = virt / ra.chunks, chunk = virt - tile * ra.chunks;
   int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
   ty = interleave_rows(ty, ra.n_tiles / ra.tiles_x);
-  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
-  int py = ra.row_begin + ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+  const int lane = threadIdx.x;
 
   Counters cnt = {0, 0, 0, 0, 0};
-  const bool in_image = px < cam.width && py < ra.row_end;
   PathParams pp;
-  pp.px = px; pp.py = py; pp.max_bounce = ra.max_bounce; pp.seed = ra.seed;
+  pp.x0 = tx * kTile; pp.y0 = ra.row_begin + ty * kTile;
+  pp.slot_bits = 6; pp.row_bits = 3;
+  pp.x_end = cam.width; pp.y_end = ra.row_end;
+  pp.max_bounce = ra.max_bounce; pp.seed = ra.seed;
   pp.samples = (ra.samples - chunk + ra.chunks - 1) / ra.chunks;  // chunk c takes samples c, c + chunks, ...
   pp.sample_first = ra.sample_first + chunk * ra.sample_stride;
   pp.sample_stride = ra.sample_stride * ra.chunks;
+  LdsAccum acc;
+  acc.base = lds_sum;
+  lds_sum[lane] = 0.0f; lds_sum[64 + lane] = 0.0f; lds_sum[128 + lane] = 0.0f;
+  __syncthreads();
   PathState ps;
-  path_init(ps, st, sc, cam, pp, in_image, cnt);
+  path_init(ps);
+  uint32_t next_item = 0;  // wave-uniform: only ever changed where all 64 lanes are active
+
+  // Hand the next work items, in lane order, to the lanes that ask for one; repeat while a lane
+  // was given an item that needs no query (a pixel slot outside the image).
+  auto refill = [&](bool need) {
+    for (;;) {
+      unsigned long long m = __ballot(need);
+      if (m == 0ull) break;
+      uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      uint32_t item = next_item + rank;
+      next_item += (uint32_t)__popcll(m);
+      if (need) need = path_begin_item(ps, st, sc, cam, pp, item, cnt);
+    }
+  };
+  refill(true);
 
   // Every lane keeps one query in flight.  The wave alternates three uniform phases:
   //   descend  - lanes at an inner node visit it, until no lane (or too few lanes) are at one;
   //   leaves   - lanes at a leaf intersect its primitives;
-  //   advance  - once enough lanes have a finished query, they shade and start their next one,
-  //              while the rest keep their traversal state (node in a register, stack in LDS).
+  //   advance  - once enough lanes have a finished query, they shade and start their next one
+  //              (the next query of the path, or the first query of a new work item), while the
+  //              rest keep their traversal state (node in a register, stack in LDS).
+  PTK_PHASE(uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
   for (;;) {
     for (;;) {
       bool want = trav_at_inner(ps.tr);
-      if (__popcll(__ballot(want)) < kDescendMin) break;
+      int n_want = __popcll(__ballot(want));
+      if (n_want < kDescendMin) break;
+      PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
+    PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(trav_at_leaf(ps.tr))); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
     if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
     else if (kDescendMin > 1 && trav_at_inner(ps.tr)) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     bool ready = ps.alive && trav_done(ps.tr);
@@ -159,20 +202,26 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     unsigned long long busy_mask = __ballot(!trav_done(ps.tr));
     if ((ready_mask | busy_mask) == 0ull) break;
     if (__popcll(ready_mask) >= kRefillMin || busy_mask == 0ull) {
-      if (ready) path_advance(ps, st, sc, cam, fl, pp, cnt);
+      PTK_PHASE(ph[5]++; ph[6] += __popcll(ready_mask);)
+      bool need = false;
+      if (ready) need = path_consume(ps, st, sc, fl, pp, acc, cnt);
+      refill(need);
     }
   }
-  if (in_image) {
+  PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);)
+  __syncthreads();
+  const int px = pp.x0 + (lane & 7), py = pp.y0 + (lane >> 3);  // lane l writes out pixel slot l
+  if (px < pp.x_end && py < pp.y_end) {
+    f4 a;
+    a.x = lds_sum[lane]; a.y = lds_sum[64 + lane]; a.z = lds_sum[128 + lane]; a.w = (float)pp.samples;
     if (ra.chunks == 1) {
       size_t i = (size_t)py * (size_t)cam.width + (size_t)px;
-      f4 a = accum[i];
-      a.x += ps.sum.x; a.y += ps.sum.y; a.z += ps.sum.z; a.w += (float)pp.samples;
-      accum[i] = a;
+      f4 b = accum[i];
+      b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+      accum[i] = b;
     } else {
       size_t rows = (size_t)(ra.row_end - ra.row_begin);
       size_t i = ((size_t)chunk * rows + (size_t)(py - ra.row_begin)) * (size_t)cam.width + (size_t)px;
-      f4 a;
-      a.x = ps.sum.x; a.y = ps.sum.y; a.z = ps.sum.z; a.w = (float)pp.samples;
       partial[i] = a;
     }
   }
@@ -333,7 +382,7 @@ static int pick_chunks(int n_tiles, int samples)
   constexpr int64_t kResidentWaves = 256 * 4 * PTK_MIN_WAVES;
   constexpr int64_t kRounds = PTK_CHUNK_ROUNDS;
   constexpr int kMinChunkSamples = PTK_CHUNK_MIN_SAMPLES;
-  int64_t waves = (int64_t)n_tiles * PTK_BLOCK_WAVES;
+  int64_t waves = (int64_t)n_tiles;
   int64_t want = (kRounds * kResidentWaves + waves - 1) / waves;
   int64_t cap = std::max(1, samples / kMinChunkSamples);
   int64_t c = std::min<int64_t>(std::min(want, cap), kMaxChunks);
@@ -357,8 +406,8 @@ int ptk_create(int device, ptk_ctx** out)
   ctx->device = device;
   e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, 8 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, kCounterSlots * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) {
     g_create_error = std::string("ptk_create: ") + hipGetErrorString(e);
     delete ctx;
@@ -495,6 +544,7 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
     return fail(ctx, PTK_ERR_INVALID, "ptk_render: samples, max_bounce, sample_first must be >= 0 and sample_stride >= 1");
   if ((int64_t)p->sample_first + (int64_t)p->samples * p->sample_stride > (int64_t)INT32_MAX)
     return fail(ctx, PTK_ERR_LIMIT, "ptk_render: sample index exceeds 2^31 - 1");
+  if (p->samples > (1 << 25)) return fail(ctx, PTK_ERR_LIMIT, "ptk_render: at most 2^25 samples per call");
   RenderArgs ra;
   ra.samples = p->samples; ra.max_bounce = p->max_bounce; ra.seed = p->seed;
   ra.sample_first = p->sample_first; ra.sample_stride = p->sample_stride;
@@ -625,9 +675,14 @@ int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
   if (!ctx || !out) return PTK_ERR_INVALID;
   int rc = ptk_synchronize(ctx);
   if (rc) return rc;
-  unsigned long long c[8];
+  unsigned long long c[kCounterSlots];
   PTK_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
   out->camera_rays = c[0]; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
+  PTK_PHASE(if (getenv("PTK_PHASE_STATS")) {
+    auto pct = [](unsigned long long lanes, unsigned long long iters) { return iters ? 100.0 * (double)lanes / (64.0 * (double)iters) : 0.0; };
+    fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes\n",
+            c[8], pct(c[9], c[8]), c[10], pct(c[11], c[10]), pct(c[12], c[10]), c[13], pct(c[14], c[13]));
+  })
   out->kernel_ms_last = ctx->ms_last; out->kernel_ms_total = ctx->ms_total; out->launches = ctx->launches;
   return PTK_OK;
 }
@@ -637,7 +692,7 @@ int ptk_reset_stats(ptk_ctx* ctx)
   if (!ctx) return PTK_ERR_INVALID;
   int rc = ptk_synchronize(ctx);
   if (rc) return rc;
-  PTK_HIP(hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  PTK_HIP(hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream));
   ctx->ms_last = ctx->ms_total = 0.0;
   ctx->launches = 0;
   return PTK_OK;

@@ -40,6 +40,29 @@ PTK_HD float length(v3 a) { return sqrtf(dot(a, a)); }
 PTK_HD v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 PTK_HD float sqf(float x) { return x * x; }
 
+// x^y for x >= 0 and (sin, cos) of an angle given in turns.  On the GPU these map to the hardware's
+// log2 / exp2 / sin / cos instructions (about 1e-6 absolute error), a few instructions instead of
+// the hundreds of the correctly rounded library routines; they only feed shading arithmetic
+// (texture gamma, sampled directions), never an intersection test.
+PTK_HD float fast_pow(float x, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+#else
+  return powf(x, y);
+#endif
+}
+PTK_HD void sincos_turns(float turns, float* s, float* c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  *s = __builtin_amdgcn_sinf(turns);
+  *c = __builtin_amdgcn_cosf(turns);
+#else
+  *s = sinf(turns * 6.28318530718f);
+  *c = cosf(turns * 6.28318530718f);
+#endif
+}
+
 PTK_HD float as_float(uint32_t u)
 {
   union { uint32_t u; float f; } c;

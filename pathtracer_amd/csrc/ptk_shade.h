@@ -51,10 +51,10 @@ PTK_HD float rnd(Rng& r)
 PTK_HD v3 ld3(const float* p) { return V3(p[0], p[1], p[2]); }
 
 // util.h:83-89 (y is the polar axis)
-PTK_HD v3 spherical_dir(float cos_theta, float sin_theta, float phi)
+PTK_HD v3 spherical_dir(float cos_theta, float sin_theta, float phi_turns)
 {
   float s, c;
-  sincosf(phi, &s, &c);
+  sincos_turns(phi_turns, &s, &c);
   return V3(c * sin_theta, cos_theta, s * sin_theta);
 }
 
@@ -63,7 +63,7 @@ PTK_HD v3 unit_vector_from(float r0, float r1)
 {
   float ct = 1.0f - 2.0f * r1;
   float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
-  return spherical_dir(ct, st, 2.0f * kPi * r0);
+  return spherical_dir(ct, st, r0);
 }
 
 PTK_HD v3 reflect(v3 I, v3 N) { return I - N * (dot(N, I) * 2.0f); }
@@ -75,7 +75,7 @@ PTK_HD v3 refract(v3 I, v3 N, float eta)
   return V3(0.0f, 0.0f, 0.0f);
 }
 
-PTK_HD v3 pow3(v3 c, float e) { return V3(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+PTK_HD v3 pow3(v3 c, float e) { return V3(fast_pow(c.x, e), fast_pow(c.y, e), fast_pow(c.z, e)); }
 
 // Orthonormal frame with local +y along the normal (local_to_world, src/util.h:63-70).
 // The reference builds it in float and inverts it numerically; the inverse of an
@@ -214,13 +214,13 @@ PTK_HD v3 bsdf_sample(const FlagView& fl, const MaterialRec& m, bool inside, v3 
     float tan2 = -alpha2 * logf(1.0f - (r1 / kPi));  // tan^2(theta)
     float ct = 1.0f / sqrtf(1.0f + tan2);
     float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
-    v3 H = spherical_dir(ct, st, 2.0f * kPi * r0);
+    v3 H = spherical_dir(ct, st, r0);
     return reflect(-wo, H);
   }
   // diffuse, :138-144: theta = acos(sqrt(r1))
   float ct = sqrtf(r1);
   float st = sqrtf(fmaxf(0.0f, 1.0f - r1));
-  return spherical_dir(ct, st, 2.0f * kPi * r0);
+  return spherical_dir(ct, st, r0);
 }
 
 // BxDF::eval, src/material.cpp:124-136
@@ -259,17 +259,22 @@ PTK_HD float luma(v3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }  // sr
 // ---------------------------------------------------------------- the path, as a per-lane state machine
 // Renderer::trace_ray (src/renderer.cpp:57-126) is a recursion whose every level makes up to two
 // closest-hit queries: the path segment itself and one shadow ray (Renderer::sample_lights,
-// src/renderer.cpp:130-171).  Here a lane owns one pixel and carries its path as explicit state,
-// so that ALL its queries -- whatever the bounce, segment or shadow -- run through one traversal
-// loop shared by the wave.  advance() is called whenever the lane's query has finished; it
-// consumes the result and sets up the lane's next query:
+// src/renderer.cpp:130-171).  Here a lane carries one path as explicit state, so that ALL its
+// queries -- whatever the bounce, segment or shadow -- run through one traversal loop shared by
+// the wave.  path_consume() is called whenever the lane's query has finished; it uses the result
+// and sets up the lane's next query:
 //
 //   segment finished, miss      -> add background, path ends
 //   segment finished, hit       -> Russian roulette, BSDF sample, emission, pick a light;
 //                                  next query = shadow ray (if a light was sampled) else next segment
 //   shadow ray finished         -> add the light's contribution if the light is what was hit;
 //                                  next query = next segment
-//   path ends                   -> accumulate, start the next sample's camera ray (or retire)
+//   path ends                   -> its radiance goes to the pixel's accumulator; the lane asks for work
+//
+// Work is handed out as items: a tile of 1 << slot_bits pixel slots times `samples` samples,
+// item k = sample (k >> slot_bits) of slot (k & mask).  A lane is not tied to a pixel: whichever
+// lane is free takes the next item, so the lanes of a wave stay busy until the whole tile is done
+// instead of each draining its own pixel's samples.
 //
 // The arithmetic in recursion order: with beta the product of rr_weight * BSDF value along the
 // path, a level contributes beta * rr_weight * (emission + direct) and a Russian-roulette kill
@@ -277,88 +282,89 @@ PTK_HD float luma(v3 c) { return dot(c, V3(0.2126f, 0.7152f, 0.0722f)); }  // sr
 struct PathState {
   Traversal tr;        // the query in flight
   Rng g;
-  v3 beta, L, sum;
+  v3 beta, L;
   v3 pending;          // shadow ray in flight: radiance to add if it reaches the light
   v3 next_d;           // shadow ray in flight: direction of the path segment that follows it
   uint32_t light_id;   // shadow ray in flight: the light it must reach
   uint32_t origin_id;  // primitive the current path vertex lies on
-  int32_t sample;      // samples finished so far
+  uint32_t slot;       // pixel slot of the tile that the path belongs to
   int32_t depth;
   bool shadow;         // the query in flight is a shadow ray
   bool prev_specular;
-  bool alive;          // false once all samples are done
+  bool alive;          // false once the tile has no work items left for this lane
 };
 
 struct PathParams {
-  int32_t px, py, samples, max_bounce, sample_first, sample_stride;
+  int32_t x0, y0;                // pixel of slot 0
+  int32_t slot_bits, row_bits;   // 1 << slot_bits slots, 1 << row_bits of them to a tile row
+  int32_t x_end, y_end;          // slots at or beyond these pixel coordinates are outside the image
+  int32_t samples, max_bounce, sample_first, sample_stride;
   uint32_t seed;
 };
 
-template <class Stack>
-PTK_HD void path_begin_sample(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
-                              const PathParams& pp, Counters& cnt)
-{
-  // a max_bounce of 0 makes every sample black without a single query (src/renderer.cpp:59-61)
-  while (ps.sample < pp.samples) {
-    uint32_t index = (uint32_t)(pp.sample_first + ps.sample * pp.sample_stride);
-    ps.g = rng_init(pp.seed, (uint32_t)(pp.py * cam.width + pp.px), index);
-    v3 o, d;
-    camera_ray(cam, pp.px, pp.py, ps.g, o, d);
-    cnt.camera_rays++;
-    if (pp.max_bounce <= 0) { ps.sample++; continue; }
-    ps.L = V3(0.0f, 0.0f, 0.0f);
-    ps.beta = V3(1.0f, 1.0f, 1.0f);
-    ps.prev_specular = false;
-    ps.shadow = false;
-    ps.depth = 0;
-    ps.origin_id = kNoPrim;
-    cnt.segments++;
-    cnt.queries++;
-    trav_begin(ps.tr, st, sc, o, d, kTMax, kNoPrim);
-    return;
-  }
-  ps.alive = false;
-  ps.tr.node = kTravDone;
-}
+struct SumAccum {  // accumulator of a one-pixel tile
+  v3 sum;
+  PTK_HD void add(uint32_t, v3 L) { sum += L; }
+};
 
-template <class Stack>
-PTK_HD void path_init(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam, const PathParams& pp,
-                      bool in_image, Counters& cnt)
+PTK_HD void path_init(PathState& ps)
 {
-  ps.sum = V3(0.0f, 0.0f, 0.0f);
   ps.L = ps.beta = ps.pending = ps.next_d = V3(0.0f, 0.0f, 0.0f);
   ps.light_id = ps.origin_id = kNoPrim;
-  ps.sample = 0;
+  ps.slot = 0;
   ps.depth = 0;
   ps.shadow = ps.prev_specular = false;
-  ps.alive = in_image;
+  ps.alive = true;
   ps.tr.node = kTravDone;
-  if (in_image) path_begin_sample(ps, st, sc, cam, pp, cnt);
 }
 
+// Give a free lane work item `item`.  Returns true when the lane is still free afterwards (the item
+// lay outside the image, or needed no query) and wants another item; false when the lane has a
+// query in flight or the items have run out (then ps.alive is false).
 template <class Stack>
-PTK_HD void path_end_sample(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
-                            const PathParams& pp, Counters& cnt)
+PTK_HD bool path_begin_item(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
+                            const PathParams& pp, uint32_t item, Counters& cnt)
 {
-  ps.sum += ps.L;
-  ps.sample++;
-  path_begin_sample(ps, st, sc, cam, pp, cnt);
+  if (item >= ((uint32_t)pp.samples << pp.slot_bits)) {
+    ps.alive = false;
+    ps.tr.node = kTravDone;
+    return false;
+  }
+  uint32_t slot = item & ((1u << pp.slot_bits) - 1u);
+  int px = pp.x0 + (int)(slot & ((1u << pp.row_bits) - 1u)), py = pp.y0 + (int)(slot >> pp.row_bits);
+  if (px >= pp.x_end || py >= pp.y_end) return true;
+  uint32_t index = (uint32_t)(pp.sample_first + (int32_t)(item >> pp.slot_bits) * pp.sample_stride);
+  ps.g = rng_init(pp.seed, (uint32_t)(py * cam.width + px), index);
+  v3 o, d;
+  camera_ray(cam, px, py, ps.g, o, d);
+  cnt.camera_rays++;
+  if (pp.max_bounce <= 0) return true;  // every sample is black without a single query (src/renderer.cpp:59-61)
+  ps.slot = slot;
+  ps.L = V3(0.0f, 0.0f, 0.0f);
+  ps.beta = V3(1.0f, 1.0f, 1.0f);
+  ps.prev_specular = false;
+  ps.shadow = false;
+  ps.depth = 0;
+  ps.origin_id = kNoPrim;
+  cnt.segments++;
+  cnt.queries++;
+  trav_begin(ps.tr, st, sc, o, d, kTMax, kNoPrim);
+  return false;
 }
 
-// Start the path segment that leaves the current vertex in direction d (or end the path at the bounce limit).
+// Start the path segment that leaves the current vertex in direction d.  Returns true when the
+// bounce limit ends the path instead.
 template <class Stack>
-PTK_HD void path_next_segment(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
-                              const PathParams& pp, const FlagView& fl, v3 d, Counters& cnt)
+PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, const PathParams& pp, const FlagView& fl,
+                              v3 d, Counters& cnt)
 {
   ps.depth++;
-  if (!fl.indirect_light_sampling || ps.depth >= pp.max_bounce) {
-    path_end_sample(ps, st, sc, cam, pp, cnt);
-    return;
-  }
+  if (!fl.indirect_light_sampling || ps.depth >= pp.max_bounce) return true;
   ps.shadow = false;
   cnt.segments++;
   cnt.queries++;
   trav_begin(ps.tr, st, sc, ps.tr.o, d, kTMax, ps.origin_id);
+  return false;
 }
 
 // Next-event estimation set-up, Renderer::sample_lights (src/renderer.cpp:130-171): one uniformly chosen
@@ -418,29 +424,22 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   return true;
 }
 
-// The lane's query has finished: consume it and set up the next one.
+// A path segment's query has finished: shade the vertex it found.  Returns true when the path ends here.
 template <class Stack>
-PTK_HD void path_advance(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam, const FlagView& fl,
-                         const PathParams& pp, Counters& cnt)
+PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
+                       Counters& cnt)
 {
-  if (ps.shadow) {
-    if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
-    path_next_segment(ps, st, sc, cam, pp, fl, ps.next_d, cnt);
-    return;
-  }
   const v3 o = ps.tr.o, d = ps.tr.d;
   if (ps.tr.hit.id == kNoPrim) {
     ps.L += ps.beta * background(sc, d);  // src/renderer.cpp:67-69
-    path_end_sample(ps, st, sc, cam, pp, cnt);
-    return;
+    return true;
   }
   Surface s;
   make_surface(sc, o, d, ps.tr.hit, s);
   const MaterialRec m = sc.materials[s.material];
   if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
     ps.L += ps.beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
-    path_end_sample(ps, st, sc, cam, pp, cnt);
-    return;
+    return true;
   }
   v3 albedo = surface_albedo(sc, m, s);
   v3 emission = ld3(m.emission);
@@ -449,8 +448,7 @@ PTK_HD void path_advance(PathState& ps, Stack& st, const SceneView& sc, const Ca
     float p = luma(albedo);
     if (rnd(ps.g) >= p) {
       ps.L += ps.beta * emission;
-      path_end_sample(ps, st, sc, cam, pp, cnt);
-      return;
+      return true;
     }
     rr_weight = 1.0f / p;
   }
@@ -473,27 +471,55 @@ PTK_HD void path_advance(PathState& ps, Stack& st, const SceneView& sc, const Ca
     cnt.queries++;
     // the light is at `distance`: nothing farther can be the closest hit that counts
     trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id);
-    return;
+    return false;
   }
-  path_next_segment(ps, st, sc, cam, pp, fl, next_d, cnt);
+  return path_next_segment(ps, st, sc, pp, fl, next_d, cnt);
 }
 
-// One lane run to completion on its own (the host-compiled checks use this; the kernel interleaves
-// the same steps across a wave).
-template <class Stack, bool STATS>
-PTK_HD v3 render_pixel(const SceneView& sc, const CameraView& cam, const FlagView& fl, const PathParams& pp, Stack& st,
-                       Counters& cnt)
+// The lane's query has finished: use its result and set up the next query of the path.  Returns
+// true when the path has ended; its radiance has then been added to the accumulator and the lane is free.
+template <class Stack, class Accum>
+PTK_HD bool path_consume(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
+                         Accum& acc, Counters& cnt)
 {
+  bool ended;
+  if (ps.shadow) {
+    if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
+    ended = path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
+  } else {
+    ended = path_shade(ps, st, sc, fl, pp, cnt);
+  }
+  if (ended) acc.add(ps.slot, ps.L);
+  return ended;
+}
+
+// One pixel run to completion by one lane on its own (the host-compiled checks use this; the
+// kernel interleaves the same steps across a wave).
+template <class Stack, bool STATS>
+PTK_HD v3 render_pixel(const SceneView& sc, const CameraView& cam, const FlagView& fl, int px, int py, int samples,
+                       int max_bounce, int sample_first, int sample_stride, uint32_t seed, Stack& st, Counters& cnt)
+{
+  PathParams pp;
+  pp.x0 = px; pp.y0 = py; pp.slot_bits = 0; pp.row_bits = 0;
+  pp.x_end = px + 1; pp.y_end = py + 1;
+  pp.samples = samples; pp.max_bounce = max_bounce; pp.sample_first = sample_first; pp.sample_stride = sample_stride;
+  pp.seed = seed;
   PathState ps;
-  path_init(ps, st, sc, cam, pp, true, cnt);
-  while (ps.alive) {
+  path_init(ps);
+  SumAccum acc;
+  acc.sum = V3(0.0f, 0.0f, 0.0f);
+  uint32_t next = 0;
+  bool need = true;
+  for (;;) {
+    while (need) need = path_begin_item(ps, st, sc, cam, pp, next++, cnt);
+    if (!ps.alive) break;
     while (!trav_done(ps.tr)) {
       if (trav_at_inner(ps.tr)) trav_inner<Stack, STATS>(ps.tr, st, sc, cnt);
       else trav_leaf<Stack, STATS>(ps.tr, st, sc, cnt);
     }
-    path_advance(ps, st, sc, cam, fl, pp, cnt);
+    need = path_consume(ps, st, sc, fl, pp, acc, cnt);
   }
-  return ps.sum;
+  return acc.sum;
 }
 
 }  // namespace ptk

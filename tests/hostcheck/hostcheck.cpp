@@ -103,10 +103,8 @@ void hc_render(void* h, const ptk_camera* camera, const ptk_flags* flags, const 
       for (int x = 0; x < cam.width; x++) {
         HostStack st;
         Counters cnt = {0, 0, 0, 0, 0};
-        PathParams pp;
-        pp.px = x; pp.py = y; pp.samples = p->samples; pp.max_bounce = p->max_bounce;
-        pp.sample_first = p->sample_first; pp.sample_stride = p->sample_stride; pp.seed = p->seed;
-        v3 sum = render_pixel<HostStack, true>(sc, cam, fl, pp, st, cnt);
+        v3 sum = render_pixel<HostStack, true>(sc, cam, fl, x, y, p->samples, p->max_bounce, p->sample_first,
+                                               p->sample_stride, p->seed, st, cnt);
         float* a = accum + 4 * ((size_t)y * cam.width + x);
         a[0] += sum.x; a[1] += sum.y; a[2] += sum.z; a[3] += (float)p->samples;
         loc[0] += cnt.camera_rays; loc[1] += cnt.segments; loc[2] += cnt.queries; loc[3] += cnt.box_tests; loc[4] += cnt.prim_tests;

@@ -43,6 +43,18 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 #ifndef PTK_CHUNK_MIN_SAMPLES
 #define PTK_CHUNK_MIN_SAMPLES 16  // ... but never below this many samples per chunk
 #endif
+#ifndef PTK_SPLIT_ADVANCE
+#define PTK_SPLIT_ADVANCE 1
+#endif
+#ifndef PTK_LIT_MIN
+#define PTK_LIT_MIN 8
+#endif
+#ifndef PTK_SHADE_MIN
+#define PTK_SHADE_MIN 24
+#endif
+#ifndef PTK_ITEM_MIN
+#define PTK_ITEM_MIN 8
+#endif
 constexpr int kMaxChunks = 32;
 constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters of a PTK_PHASE_STATS build
 
@@ -58,14 +70,20 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 constexpr int kRefillMin = PTK_REFILL_MIN;
 
 struct LdsStack {
-  uint32_t* base;  // this lane's column of the workgroup's LDS array
-  int sp;
-  __device__ __forceinline__ void reset() { base[0] = (uint32_t)kTravDone; sp = 1; }
-  __device__ __forceinline__ void push(uint32_t v)
+  uint32_t* top;   // this lane's top entry in the workgroup's LDS array (entries of a lane are kBlock words apart)
+  uint32_t* base;  // this lane's entry 0
+  __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
+  __device__ __forceinline__ void push(uint32_t v) { top += kBlock; *top = v; }
+  __device__ __forceinline__ uint32_t pop() { uint32_t v = *top; top -= kBlock; return v; }
+  // Branch-free: the entry above the top is scratch, so v is always written there and only counts
+  // if the top moves up.  The builder keeps trees shallower than the stack (ptk_upload_scene checks).
+  __device__ __forceinline__ uint32_t step(bool do_push, uint32_t v, bool do_pop)
   {
-    if (sp < kStackDepth) { base[sp * kBlock] = v; sp++; }  // the builder keeps trees shallower than the stack
+    uint32_t t = *top;
+    top[kBlock] = v;
+    top += (do_push ? kBlock : 0) - (do_pop ? kBlock : 0);
+    return t;
   }
-  __device__ __forceinline__ uint32_t pop() { sp--; return base[sp * kBlock]; }
 };
 
 // Per-pixel radiance sums of a tile, in LDS.  Two lanes can finish paths of the same pixel in the
@@ -136,8 +154,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
-  st.base = lds_stack + threadIdx.x;
-  st.sp = 0;
+  st.base = st.top = lds_stack + threadIdx.x;
 
   // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
   // tile, then the next tile of the same tile row; tile rows are dealt to the XCDs round-robin
@@ -186,6 +203,39 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   //              (the next query of the path, or the first query of a new work item), while the
   //              rest keep their traversal state (node in a register, stack in LDS).
   PTK_PHASE(uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
+#if PTK_SPLIT_ADVANCE
+  bool need = false;  // this lane's path has ended and it has not been given a new work item yet
+  for (;;) {
+    for (;;) {
+      bool want = trav_at_inner(ps.tr);
+      int n_want = __popcll(__ballot(want));
+      if (n_want < kDescendMin) break;
+      PTK_PHASE(ph[0]++; ph[1] += n_want;)
+      if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    }
+    PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(trav_at_leaf(ps.tr))); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
+    if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    else if (kDescendMin > 1 && trav_at_inner(ps.tr)) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    const bool done = trav_done(ps.tr);
+    const bool waiting = ps.alive && done && !need;
+    const bool lit = waiting && ps.shadow, shade = waiting && !ps.shadow;
+    const int n_lit = __popcll(__ballot(lit)), n_shade = __popcll(__ballot(shade));
+    const bool idle = __ballot(!done) == 0ull;  // no lane is traversing: everything that waits must run now
+    if (idle && n_lit + n_shade + __popcll(__ballot(need)) == 0) break;
+    if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
+      if (lit && path_consume_shadow(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot, ps.L); need = true; }
+    }
+    if (n_shade >= PTK_SHADE_MIN || (idle && n_shade > 0)) {
+      PTK_PHASE(ph[5]++; ph[6] += n_shade;)
+      if (shade && path_shade(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot, ps.L); need = true; }
+    }
+    const int n_need = __popcll(__ballot(need));
+    if (n_need >= PTK_ITEM_MIN || (idle && n_need > 0)) {
+      refill(need);
+      need = false;
+    }
+  }
+#else
   for (;;) {
     for (;;) {
       bool want = trav_at_inner(ps.tr);
@@ -208,6 +258,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       refill(need);
     }
   }
+#endif
   PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);)
   __syncthreads();
   const int px = pp.x0 + (lane & 7), py = pp.y0 + (lane >> 3);  // lane l writes out pixel slot l
@@ -249,8 +300,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   LdsStack st;
-  st.base = lds_stack + threadIdx.x;
-  st.sp = 0;
+  st.base = st.top = lds_stack + threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
   int i = (int)(blockIdx.x * kBlock + threadIdx.x);
   if (i < n) {
@@ -444,6 +494,9 @@ int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
   free_scene(ctx);
   std::string why = build_host_scene(*scene, ctx->host);
   if (!why.empty()) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: " + why);
+  // the kernels' per-lane stacks hold kStackDepth entries: a sentinel, one per level, one of scratch
+  if (ctx->host.max_depth > kMaxTreeDepth || kMaxTreeDepth + 2 > kStackDepth)
+    return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
   HostScene& h = ctx->host;
   int rc;
   if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;

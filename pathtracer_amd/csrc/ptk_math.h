@@ -36,9 +36,27 @@ PTK_HD v3& operator*=(v3& a, v3 b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; return 
 PTK_HD v3& operator*=(v3& a, float s) { a.x *= s; a.y *= s; a.z *= s; return a; }
 PTK_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PTK_HD v3 cross(v3 a, v3 b) { return v3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
-PTK_HD float length(v3 a) { return sqrtf(dot(a, a)); }
-PTK_HD v3 normalize(v3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 PTK_HD float sqf(float x) { return x * x; }
+
+// 1/x and 1/sqrt(x): on the GPU the hardware's 1-ulp reciprocal instructions, one instruction each.
+PTK_HD float frcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+PTK_HD float frsq(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+PTK_HD float length(v3 a) { return sqrtf(dot(a, a)); }
+PTK_HD v3 normalize(v3 a) { return a * frsq(dot(a, a)); }
 
 // x^y for x >= 0 and (sin, cos) of an angle given in turns.  On the GPU these map to the hardware's
 // log2 / exp2 / sin / cos instructions (about 1e-6 absolute error), a few instructions instead of

@@ -397,7 +397,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   }
   v3 to_light = q - s.point;
   float distance = length(to_light);
-  to_light = to_light * (1.0f / distance);
+  to_light = to_light * frcp(distance);
   if (s.id == light.id) return false;  // src/renderer.cpp:146 (the reference traces the ray first; the result is unused)
   if (light.kind == kSphere) {
     // The shadow ray meets the sphere at its FIRST intersection, which is not the sampled point when that
@@ -415,7 +415,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   v3 wo = to_local(fr, -incoming);
   v3 wi = to_local(fr, to_light);
   float light_cos = fmaxf(dot(normal, -to_light), 0.0f);
-  float weight = light.area * light_cos / (distance * distance);
+  float weight = light.area * light_cos * frcp(distance * distance);
   v3 f = bsdf_eval(fl, m, albedo, wo, wi);
   ps.pending = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
   ps.light_id = light.id;
@@ -450,7 +450,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
       ps.L += ps.beta * emission;
       return true;
     }
-    rr_weight = 1.0f / p;
+    rr_weight = frcp(p);
   }
   Frame fr = make_frame(s.normal);
   v3 wo = to_local(fr, -d);
@@ -474,6 +474,16 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     return false;
   }
   return path_next_segment(ps, st, sc, pp, fl, next_d, cnt);
+}
+
+// A shadow ray's query has finished: add the light's contribution if the light is what it reached,
+// then start the path's next segment.  Returns true when the path ends here.
+template <class Stack>
+PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
+                                Counters& cnt)
+{
+  if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
+  return path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
 }
 
 // The lane's query has finished: use its result and set up the next query of the path.  Returns

@@ -43,7 +43,7 @@ PTK_HD bool hit_triangle(const PrimRec& p, v3 o, v3 d, float tbest, float& t, fl
   v3 pvec = cross(d, e2);
   float det = dot(e1, pvec);
   if (fabsf(det) < kTMin) return false;
-  float inv = 1.0f / det;
+  float inv = frcp(det);
   v3 tvec = o - v0;
   float uu = dot(tvec, pvec) * inv;
   v3 qvec = cross(tvec, e1);
@@ -66,7 +66,7 @@ PTK_HD bool hit_sphere(const PrimRec& p, v3 o, v3 d, float tbest, bool own_surfa
   float r = p.a.w;
   float a = dot(d, d);
   float h = dot(d, oc);
-  float inv_a = 1.0f / a;
+  float inv_a = frcp(a);
   float root;
   if (own_surface) {
     root = 2.0f * h * inv_a;
@@ -110,8 +110,9 @@ PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float
 // as separate uniform loops, and lets a lane whose query has finished pick up its next ray
 // while its neighbours are still traversing.
 //
-// Stack: reset(), push(uint32_t), pop() -> uint32_t.  reset() leaves kTravDone at the bottom,
-// so popping an exhausted stack yields the "finished" node.
+// Stack: reset(), pop() -> uint32_t, and step(do_push, v, do_pop) -> the top entry as it was before the
+// call, after which v has been pushed or the top popped as asked (never both).  reset() leaves kTravDone
+// at the bottom, so popping an exhausted stack yields the "finished" node.
 constexpr int32_t kTravDone = (int32_t)0x80000000;  // not a valid leaf code for < 2^28 primitives
 
 struct Traversal {
@@ -132,8 +133,8 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   // 1/d is kept finite: with an infinite 1/d the fused form below would turn "inf - inf" into NaN for one
   // plane of a slab that contains the origin.  1e20 keeps every product far inside the float range.
   const float big = 1e20f;
-  tr.inv = V3(fmaxf(fminf(1.0f / d.x, big), -big), fmaxf(fminf(1.0f / d.y, big), -big),
-              fmaxf(fminf(1.0f / d.z, big), -big));
+  tr.inv = V3(fmaxf(fminf(frcp(d.x), big), -big), fmaxf(fminf(frcp(d.y), big), -big),
+              fmaxf(fminf(frcp(d.z), big), -big));
   tr.oi = o * tr.inv;
   tr.hit.t = tmax;
   tr.hit.id = kNoPrim;
@@ -144,21 +145,25 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   tr.node = sc.n_prims > 0 ? 0 : kTravDone;
 }
 
+// Visit one inner node.  Straight-line code: whether a child is pushed, and whether the next node
+// comes from the stack, are decided by selects, and the stack is touched the same way every time
+// (Stack::step reads the top entry, writes the candidate above it and then moves the stack pointer).
 template <class Stack, bool STATS>
 PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
 {
-  const NodePair n = sc.nodes[tr.node];
+  // a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address arithmetic
+  // (loaded whole, by value: the child links must not become a second, dependent fetch)
+  const NodePair n = *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) +
+                                                         ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)));
   float tn0, tn1;
   bool h0 = hit_box(n.xy0.x, n.xy0.y, n.xy0.z, n.xy0.w, n.zz.x, n.zz.y, tr.oi, tr.inv, tr.hit.t, tn0);
   bool h1 = hit_box(n.xy1.x, n.xy1.y, n.xy1.z, n.xy1.w, n.zz.z, n.zz.w, tr.oi, tr.inv, tr.hit.t, tn1);
   if (STATS) cnt.box_tests += 2;
-  if (h0 && h1) {
-    bool swap = tn1 < tn0;
-    st.push((uint32_t)(swap ? n.child0 : n.child1));
-    tr.node = swap ? n.child1 : n.child0;
-  } else if (h0) tr.node = n.child0;
-  else if (h1) tr.node = n.child1;
-  else tr.node = (int32_t)st.pop();
+  const bool both = h0 & h1, none = !(h0 | h1);
+  const bool first1 = h1 & (!h0 | (tn1 < tn0));  // child 1 is the one to visit first
+  const int32_t near = first1 ? n.child1 : n.child0, far = first1 ? n.child0 : n.child1;
+  const uint32_t top = st.step(both, (uint32_t)far, none);
+  tr.node = none ? (int32_t)top : near;
 }
 
 template <class Stack, bool STATS>

@@ -26,6 +26,13 @@ struct HostStack {
     if (sp > high_water) high_water = sp;
   }
   uint32_t pop() { return data[--sp]; }
+  uint32_t step(bool do_push, uint32_t v, bool do_pop)
+  {
+    uint32_t top = data[sp - 1];
+    if (do_push) push(v);
+    if (do_pop) sp--;
+    return top;
+  }
 };
 
 struct Check {

@@ -1,11 +1,13 @@
 // HIP kernels for gfx950 and the C ABI of include/ptk.h.
 //
-// One lane per path.  A 256-thread workgroup renders a 16x16 pixel tile; each
-// of its four waves owns an 8x8 sub-tile so that the 64 primary rays of a wave
-// are neighbours.  The traversal stack lives in LDS, strided by lane
-// (stack[level][lane]) so that all 64 lanes of a push or pop touch different
-// banks.  Workgroup ids are remapped so that the workgroups that share an XCD
-// (and its L2) render adjacent tiles.
+// One lane per path.  A one-wave workgroup renders an 8x8 pixel tile (or one chunk of its
+// samples): the tile's (pixel, sample) pairs are a pool of work items that the wave's 64 lanes
+// draw from, so the primary rays of a refill are neighbours and no lane idles while another
+// still has samples to do.  The traversal stack lives in LDS, strided by lane
+// (stack[level][lane]) so that all 64 lanes of a push or pop touch different banks; the tile's
+// pixel sums live in LDS too.  Workgroup ids are remapped so that the workgroups that share an
+// XCD (and its L2) render the chunks of one tile, then the neighbouring tile, and so that every
+// XCD gets an equal share of every part of the image.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -25,35 +27,34 @@ namespace ptk {
 constexpr int kBlock = 64;  // one wave per workgroup: a finished wave frees its slot at once
 constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 
-// Wave scheduling knobs of the render kernel (see its main loop).
-// Measured on the 81,920-triangle mesh scene (1024x1024, 64 spp, 3 bounces; Mrays/s): strict
-// while-while (descend 1) 2.5k; descend 16 / refill 32 3.4k; descend 32 3.2k; descend 64 2.6k.
+// Wave scheduling knobs of the render kernel (see its main loop).  Measured on the 81,920-triangle
+// mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: same,
+// 24: -4%, 32: -6%; lit 16: -9%, 4: -1%; shade 32: -9%, 16: -4%; item 16: -9%, 1: -6%; 3 waves
+// per SIMD: same, 5 (96 VGPRs, spills): -4%.
 #ifndef PTK_DESCEND_MIN
 #define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
 #endif
-#ifndef PTK_REFILL_MIN
-#define PTK_REFILL_MIN 32   // shade / refill once at least this many lanes have a finished query
+#ifndef PTK_LIT_MIN
+#define PTK_LIT_MIN 8       // consume finished shadow rays once this many lanes hold one
+#endif
+#ifndef PTK_SHADE_MIN
+#define PTK_SHADE_MIN 24    // shade once this many lanes hold a finished path segment
+#endif
+#ifndef PTK_ITEM_MIN
+#define PTK_ITEM_MIN 8      // hand out work items once this many lanes are free
 #endif
 #ifndef PTK_MIN_WAVES
-#define PTK_MIN_WAVES 4     // __launch_bounds__ waves per SIMD for the render kernel (3: 3.47k, 4: 3.79k, 5: 3.03k Mrays/s)
+#define PTK_MIN_WAVES 4     // __launch_bounds__ waves per SIMD for the render kernel
 #endif
+// A frame whose tiles alone give the chip only a few rounds of waves ends with most CUs idle
+// while the slowest tiles finish, so a tile's samples are split over several workgroups.
+// 1024x1024, 1024 spp: 1 chunk 4.9k, 2: 6.1k, 4: 6.9k, 8: 7.1k, 16: 6.9k Mrays/s (before the
+// work-item pool; with it the optimum is flat between 8 and 32).
 #ifndef PTK_CHUNK_ROUNDS
 #define PTK_CHUNK_ROUNDS 32       // split tiles into sample chunks until the grid is this many times the resident waves
 #endif
 #ifndef PTK_CHUNK_MIN_SAMPLES
 #define PTK_CHUNK_MIN_SAMPLES 16  // ... but never below this many samples per chunk
-#endif
-#ifndef PTK_SPLIT_ADVANCE
-#define PTK_SPLIT_ADVANCE 1
-#endif
-#ifndef PTK_LIT_MIN
-#define PTK_LIT_MIN 8
-#endif
-#ifndef PTK_SHADE_MIN
-#define PTK_SHADE_MIN 24
-#endif
-#ifndef PTK_ITEM_MIN
-#define PTK_ITEM_MIN 8
 #endif
 constexpr int kMaxChunks = 32;
 constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters of a PTK_PHASE_STATS build
@@ -67,7 +68,6 @@ constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phas
 #define PTK_PHASE(...)
 #endif
 constexpr int kDescendMin = PTK_DESCEND_MIN;
-constexpr int kRefillMin = PTK_REFILL_MIN;
 
 struct LdsStack {
   uint32_t* top;   // this lane's top entry in the workgroup's LDS array (entries of a lane are kBlock words apart)
@@ -196,14 +196,17 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   };
   refill(true);
 
-  // Every lane keeps one query in flight.  The wave alternates three uniform phases:
-  //   descend  - lanes at an inner node visit it, until no lane (or too few lanes) are at one;
-  //   leaves   - lanes at a leaf intersect its primitives;
-  //   advance  - once enough lanes have a finished query, they shade and start their next one
-  //              (the next query of the path, or the first query of a new work item), while the
-  //              rest keep their traversal state (node in a register, stack in LDS).
+  // Every lane keeps one query in flight.  The wave alternates uniform phases, each run only when
+  // enough lanes want it (or when no lane is traversing any more, so that everything drains):
+  //   descend  - lanes at an inner node visit it, repeated while at least kDescendMin lanes are at one;
+  //   leaves   - lanes at a leaf intersect its primitives (the few lanes still at an inner node take
+  //              one more step beside them);
+  //   lit      - lanes whose shadow ray has finished add the light and start the path's next segment;
+  //   shade    - lanes whose path segment has finished shade the hit and start a shadow ray or the
+  //              next segment;
+  //   refill   - lanes whose path has ended take the tile's next work items.
+  // Lanes not in the running phase keep their state (node in a register, stack in LDS).
   PTK_PHASE(uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
-#if PTK_SPLIT_ADVANCE
   bool need = false;  // this lane's path has ended and it has not been given a new work item yet
   for (;;) {
     for (;;) {
@@ -235,30 +238,6 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       need = false;
     }
   }
-#else
-  for (;;) {
-    for (;;) {
-      bool want = trav_at_inner(ps.tr);
-      int n_want = __popcll(__ballot(want));
-      if (n_want < kDescendMin) break;
-      PTK_PHASE(ph[0]++; ph[1] += n_want;)
-      if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
-    }
-    PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(trav_at_leaf(ps.tr))); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
-    if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
-    else if (kDescendMin > 1 && trav_at_inner(ps.tr)) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
-    bool ready = ps.alive && trav_done(ps.tr);
-    unsigned long long ready_mask = __ballot(ready);
-    unsigned long long busy_mask = __ballot(!trav_done(ps.tr));
-    if ((ready_mask | busy_mask) == 0ull) break;
-    if (__popcll(ready_mask) >= kRefillMin || busy_mask == 0ull) {
-      PTK_PHASE(ph[5]++; ph[6] += __popcll(ready_mask);)
-      bool need = false;
-      if (ready) need = path_consume(ps, st, sc, fl, pp, acc, cnt);
-      refill(need);
-    }
-  }
-#endif
   PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);)
   __syncthreads();
   const int px = pp.x0 + (lane & 7), py = pp.y0 + (lane >> 3);  // lane l writes out pixel slot l

@@ -40,20 +40,20 @@ PTK_HD bool hit_triangle(const PrimRec& p, v3 o, v3 d, float tbest, float& t, fl
   v3 v0 = V3(p.a.x, p.a.y, p.a.z);
   v3 e1 = V3(p.a.w, p.b.x, p.b.y);
   v3 e2 = V3(p.b.z, p.b.w, p.c.x);
+  // Straight-line: every quantity is computed and the acceptance tests are combined at the end
+  // (a wave would run all of it anyway as soon as one lane passes each test).  A zero det makes
+  // inv infinite and the comparisons, all written to fail on NaN, reject.
   v3 pvec = cross(d, e2);
   float det = dot(e1, pvec);
-  if (fabsf(det) < kTMin) return false;
   float inv = frcp(det);
   v3 tvec = o - v0;
   float uu = dot(tvec, pvec) * inv;
   v3 qvec = cross(tvec, e1);
   float vv = dot(d, qvec) * inv;
   float tt = dot(e2, qvec) * inv;
-  // edge functions >= 0  <=>  u >= 0, v >= 0, 1-u-v >= 0
-  if (!(uu >= 0.0f && vv >= 0.0f && uu + vv <= 1.0f)) return false;
-  if (!(tt >= kTMin && tt < tbest)) return false;
   t = tt; u = uu; v = vv;
-  return true;
+  // edge functions >= 0  <=>  u >= 0, v >= 0, 1-u-v >= 0
+  return (fabsf(det) >= kTMin) & (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt >= kTMin) & (tt < tbest);
 }
 
 // Roots of |o + t d - c|^2 = r^2 as (h -+ sqrt(disc)) / a with h = d.(c-o), evaluated from the
@@ -166,23 +166,44 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   tr.node = none ? (int32_t)top : near;
 }
 
+// Test one primitive record against the lane's ray and keep it if it is the closest hit so far.
+template <bool STATS>
+PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
+{
+  const uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
+  if (STATS) cnt.prim_tests++;
+  float t = 0.0f, u = 0.0f, v = 0.0f;
+  bool ok;
+  if (kind == kTriangle) {
+    // a triangle the ray starts on is not a candidate (see the note at the top of this file)
+    ok = hit_triangle(p, tr.o, tr.d, tr.hit.t, t, u, v) & (id != tr.skip_id);
+  } else {
+    ok = hit_sphere(p, tr.o, tr.d, tr.hit.t, id == tr.skip_id, t);
+    u = v = 0.0f;
+  }
+  if (ok) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = u; tr.hit.v = v; }
+}
+
+PTK_HD PrimRec load_prim(const SceneView& sc, uint32_t byte_offset)  // 32-bit byte offset, as for the nodes
+{
+  return *reinterpret_cast<const PrimRec*>(reinterpret_cast<const char*>(sc.prims) + byte_offset);
+}
+
+// Intersect the primitives of one leaf.
 template <class Stack, bool STATS>
 PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
 {
-  uint32_t leaf = ~(uint32_t)tr.node;
-  uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+  const uint32_t leaf = ~(uint32_t)tr.node;
+  const uint32_t count = (leaf & 7u) + 1u;
+  uint32_t off = (leaf >> 3) * (uint32_t)sizeof(PrimRec);
+  // the next record is fetched while this one is tested
+  PrimRec p = load_prim(sc, off);
   for (uint32_t i = 0; i < count; i++) {
-    const PrimRec p = sc.prims[first + i];
-    uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
-    if (STATS) cnt.prim_tests++;
-    if (kind == kTriangle) {
-      if (id == tr.skip_id) continue;
-      float t, u, v;
-      if (hit_triangle(p, tr.o, tr.d, tr.hit.t, t, u, v)) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = u; tr.hit.v = v; }
-    } else {
-      float t;
-      if (hit_sphere(p, tr.o, tr.d, tr.hit.t, id == tr.skip_id, t)) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = tr.hit.v = 0.0f; }
-    }
+    PrimRec next = p;
+    off += (uint32_t)sizeof(PrimRec);
+    if (i + 1 < count) next = load_prim(sc, off);
+    trav_test_prim<STATS>(tr, p, cnt);
+    p = next;
   }
   tr.node = (int32_t)st.pop();
 }

@@ -32,7 +32,11 @@ WORKLOADS = {
     "bunny": "Cornell box + 81,920-triangle smooth mesh (bunny-class stand-in: diffuse + emissive area light)",
     "cornell": "Cornell box OBJ (12 triangles, textured floor, depth of field)",
     "bmw": "Cornell box + 1,310,720-triangle mesh (BMW-class stand-in)",
+    "envmap": "Cornell box (textured floor) + 81,920-triangle mesh, 3584x1792 environment map, depth of field",
+    "glass": "Cornell box + dielectric 20,480-triangle mesh + glass and mirror spheres (Russian roulette active)",
 }
+# per-workload defaults for (width, height, spp, bounces) where they differ from the command line's
+WORKLOAD_DEFAULTS = {"envmap": (1920, 1080, 1024, 3), "glass": (500, 500, 2048, 8)}
 
 
 def build_scene(name, width, height):
@@ -43,22 +47,30 @@ def build_scene(name, width, height):
         return scenes.cornell_with_mesh(8, width, height)
     if name == "cornell":
         return scenes.cornell_box(width, height)
+    if name == "envmap":
+        return scenes.cornell_with_mesh(6, width, height, envmap=scenes.procedural_envmap())
+    if name == "glass":
+        return scenes.glass_scene(5, width, height)
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(sd, spp_budget_s=12.0):
+def cpu_baseline(sd, budget_s=15.0):
     """The CPU oracle (a restatement of the reference renderer) timed on this box's host cores on a bounded
-    sample of the same workload: a band of rows in the middle of the frame."""
+    sample of the same workload: a band of rows in the middle of the frame, sized from a one-sample probe so
+    that the timed run takes about budget_s seconds."""
     from oracle import orc
     o = orc.OracleScene(sd)
     h = sd.camera.height
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
     band = max(8, min(h, 64))
     y0 = (h - band) // 2
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
     t = time.perf_counter()
-    _, c1 = o.render(1, ARGS.bounces, seed=99, rows=(y0, y0 + band), threads=threads)
-    t1 = time.perf_counter() - t
-    spp = int(max(1, min(256, spp_budget_s / max(t1, 1e-3))))
+    o.render(1, ARGS.bounces, seed=99, rows=(y0, y0 + band), threads=threads)
+    t1 = max(time.perf_counter() - t, 1e-4)  # one sample per pixel of the probe band
+    spp = int(max(1, min(ARGS.spp, budget_s / t1)))
+    if spp == ARGS.spp:  # the band at full spp is still short: widen it
+        band = int(max(band, min(h, band * budget_s / (t1 * spp))))
+        y0 = (h - band) // 2
     t = time.perf_counter()
     _, c = o.render(spp, ARGS.bounces, seed=100, rows=(y0, y0 + band), threads=threads)
     dt = time.perf_counter() - t
@@ -151,13 +163,16 @@ def main():
         kernel_s = (st["kernel_ms_total"] / max(1, st["launches"])) / 1e3
         achieved_gbs = rays_per_launch * bytes_per_ray / kernel_s / 1e9
         achieved_tf = rays_per_launch * flops_per_ray / kernel_s / 1e12
-        traffic = None
+        # memory-side bytes per launch of this exact configuration, from the hardware-counter passes whose
+        # summary is committed under profiles/ (tools/profile.sh + tools/make_traffic.py); null for others
+        traffic, l2_hit = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{ARGS.workload}_{ARGS.width}x{ARGS.height}_{ARGS.spp}spp"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                l2_hit = tj.get(key, {}).get("l2_hit_rate")
             except Exception:
                 traffic = None
         out = {
@@ -174,6 +189,10 @@ def main():
             "rays_per_segment": queries / max(1.0, segments),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved_gbs / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray, "l2_hit_rate": l2_hit,
+                         "note": "achieved counts every box and primitive test as bytes fetched; the scene is "
+                                 "cache resident (traffic << algorithmic bytes), so frac can exceed 1 and the "
+                                 "kernel is VALU-issue bound: see fp32_valu and profiles/",
                          "kernel": "render_kernel", "kernel_ms_avg": kernel_s * 1e3,
                          "bytes_per_ray": bytes_per_ray, "box_tests_per_ray": box_per_ray,
                          "prim_tests_per_ray": prim_per_ray, "rays_per_launch": rays_per_launch,
@@ -195,10 +214,10 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--bounces", type=int, default=3)
+    ap.add_argument("--width", type=int, default=None, help="default 1024 (workloads envmap and glass have their own)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU, default 1024")
+    ap.add_argument("--bounces", type=int, default=None, help="default 3")
     ap.add_argument("--batch", type=int, default=0, help="samples per launch (0 = the whole frame in one launch)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--stats-spp", type=int, default=4, help="samples per pixel of the instrumented (test-counting) pass")
@@ -206,4 +225,9 @@ if __name__ == "__main__":
                     help="how N > 1 GPUs share a frame: interleaved sample indices or interleaved row bands")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ARGS = ap.parse_args()
+    _w, _h, _s, _b = WORKLOAD_DEFAULTS.get(ARGS.workload, (1024, 1024, 1024, 3))
+    ARGS.width = ARGS.width or _w
+    ARGS.height = ARGS.height or _h
+    ARGS.spp = ARGS.spp or _s
+    ARGS.bounces = ARGS.bounces if ARGS.bounces is not None else _b
     main()

@@ -177,6 +177,10 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* params);
  * row 0 = top, W*H*3 floats, host memory.  Blocks until rendering has finished.
  * total_samples (may be NULL) receives the largest per-pixel sample count. */
 int ptk_read_accum(ptk_ctx* ctx, float* rgb, int32_t* total_samples);
+/* -- the per-pixel work of Renderer::save_image (src/renderer.cpp:174-192: mean, ACES curve, gamma
+ * 1/2.2, clamp, * 255 truncated to a byte) done on the device: W*H*3 bytes, row 0 = top, host
+ * memory.  The same bytes that the reference's loop gives from ptk_read_accum's floats.  Blocks. */
+int ptk_read_display_u8(ptk_ctx* ctx, uint8_t* rgb8, int32_t* total_samples);
 int ptk_synchronize(ptk_ctx* ctx);
 
 /* -- Scene::find_intersection (src/scene.cpp:19) over a batch of rays.

@@ -303,6 +303,36 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
   flush_counters(cnt, counters);
 }
 
+// What Renderer::save_image does to every pixel before the file is written (src/renderer.cpp:174-192):
+// mean radiance -> ACES curve -> gamma 1/2.2 -> clamp to [0,1] -> * 255, truncated.  Double
+// arithmetic as there; the mean is formed exactly as ptk_read_accum forms it on the host (fp32
+// reciprocal and product, obtained here through double so that the fast fp32 division of this
+// build cannot change a bit).  Only the W*H*3 bytes then cross PCIe instead of W*H*16.
+__global__ __launch_bounds__(256) void display_kernel(const f4* __restrict__ accum, uint8_t* __restrict__ out, size_t n,
+                                                      unsigned int* max_w_bits)
+{
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  float w = 0.f;
+  if (i < n) {
+    const f4 a = accum[i];
+    w = a.w;
+    const float inv = w > 0.f ? (float)(1.0 / (double)w) : 0.f;
+    const float mean[3] = {(float)((double)a.x * (double)inv), (float)((double)a.y * (double)inv),
+                           (float)((double)a.z * (double)inv)};
+    for (int k = 0; k < 3; k++) {
+      double c = (double)mean[k];
+      c = (c * (2.51 * c + 0.03)) / (c * (2.43 * c + 0.59) + 0.14);  // Narkowicz ACES fit, src/renderer.cpp:174-178
+      c = pow(c, 1.0 / 2.2);                                         // gamma_correction, src/util.h:131-134
+      double q = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);                // map_pixel, src/renderer.cpp:10
+      if (!(c == c)) q = 0.0;
+      out[3 * i + k] = (uint8_t)(q * 255.0);
+    }
+  }
+  unsigned int bits = __float_as_uint(fmaxf(w, 0.f));  // non-negative floats order like their bit patterns
+  for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off, 64));
+  if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_w_bits, bits);
+}
+
 }  // namespace ptk
 
 // ======================================================================== C ABI
@@ -326,6 +356,8 @@ struct ptk_ctx {
   f4* d_accum_own = nullptr;
   f4* d_accum = nullptr;  // own or bound
   size_t accum_pixels = 0;
+  uint8_t* d_display = nullptr;  // W*H*3 display bytes staged for ptk_read_display_u8
+  size_t display_capacity = 0;   // in pixels
   f4* d_partial = nullptr;  // per-chunk partial sums of the frame being rendered
   size_t partial_capacity = 0;  // in f4
   // counters and timing
@@ -454,6 +486,7 @@ int ptk_destroy(ptk_ctx* ctx)
   free_scene(ctx);
   if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_display) (void)hipFree(ctx->d_display);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -596,6 +629,7 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
     if (need > ctx->partial_capacity) {
       PTK_HIP(hipStreamSynchronize(ctx->stream));  // an earlier frame may still be folding the old buffer
       if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+  if (ctx->d_display) (void)hipFree(ctx->d_display);
       ctx->d_partial = nullptr;
       ctx->partial_capacity = 0;
       PTK_HIP(hipMalloc((void**)&ctx->d_partial, need * sizeof(f4)));
@@ -649,6 +683,35 @@ int ptk_read_accum(ptk_ctx* ctx, float* rgb, int32_t* total_samples)
     rgb[3 * i + 0] = tmp[i].x * inv; rgb[3 * i + 1] = tmp[i].y * inv; rgb[3 * i + 2] = tmp[i].z * inv;
     if (w > max_w) max_w = w;
   }
+  if (total_samples) *total_samples = (int32_t)max_w;
+  return PTK_OK;
+}
+
+int ptk_read_display_u8(ptk_ctx* ctx, uint8_t* rgb8, int32_t* total_samples)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!rgb8) return fail(ctx, PTK_ERR_INVALID, "ptk_read_display_u8: rgb8 is NULL");
+  if (!ctx->have_camera) return fail(ctx, PTK_ERR_INVALID, "ptk_read_display_u8: set the camera first");
+  PTK_HIP(hipSetDevice(ctx->device));
+  const size_t n = ctx->accum_pixels;
+  if (ctx->display_capacity < n) {
+    PTK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_display) (void)hipFree(ctx->d_display);
+    ctx->d_display = nullptr;
+    ctx->display_capacity = 0;
+    PTK_HIP(hipMalloc((void**)&ctx->d_display, n * 3 + 8));  // + the largest sample count, 4-byte aligned
+    ctx->display_capacity = n;
+  }
+  float* d_max_w = (float*)(ctx->d_display + ((n * 3 + 3) & ~(size_t)3));
+  PTK_HIP(hipMemsetAsync(d_max_w, 0, sizeof(float), ctx->stream));
+  hipLaunchKernelGGL(display_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_display, n,
+                     (unsigned int*)d_max_w);
+  PTK_HIP(hipGetLastError());
+  float max_w = 0.f;
+  PTK_HIP(hipMemcpyAsync(rgb8, ctx->d_display, n * 3, hipMemcpyDeviceToHost, ctx->stream));
+  PTK_HIP(hipMemcpyAsync(&max_w, d_max_w, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  int rc = ptk_synchronize(ctx);
+  if (rc) return rc;
   if (total_samples) *total_samples = (int32_t)max_w;
   return PTK_OK;
 }

@@ -78,38 +78,17 @@ std::vector<float> Renderer::read_buffer()
   return rgb;
 }
 
-// Narkowicz 2015, "ACES Filmic Tone Mapping Curve" (src/renderer.cpp:174-178)
-static double aces_tone_map(double x)
-{
-  const double a = 2.51, b = 0.03, c = 2.43, d = 0.59, e = 0.14;
-  return (x * (a * x + b)) / (x * (c * x + d) + e);
-}
-
-// src/renderer.cpp:10: clamp to [0,1], scale by 255, truncate
-static uint8_t map_pixel(double color)
-{
-  double c = color < 0.0 ? 0.0 : (color > 1.0 ? 1.0 : color);
-  if (!(color == color)) c = 0.0;
-  return static_cast<uint8_t>(c * 255.0);
-}
-
-// src/renderer.cpp:180-201
+// src/renderer.cpp:180-201.  The per-pixel work (mean, ACES curve of src/renderer.cpp:174-178, gamma 1/2.2 of
+// src/util.h:131-134, map_pixel of src/renderer.cpp:10) runs on the device; W*H*3 bytes come back.
 void Renderer::save_image(const std::filesystem::path& path)
 {
-  std::vector<float> rgb = read_buffer();
+  ptk_ctx* ctx = m_scene->context();
+  std::vector<uint8_t> rgb8((size_t)m_camera->width() * (size_t)m_camera->height() * 3);
+  check(ctx, ptk_read_display_u8(ctx, rgb8.data(), nullptr), "ptk_read_display_u8");
   Image output(m_camera->width(), m_camera->height(), 3);
-  for (int y = 0; y < m_camera->height(); y++) {
-    for (int x = 0; x < m_camera->width(); x++) {
-      unsigned char pixel[3];
-      for (int k = 0; k < 3; k++) {
-        double color = rgb[((size_t)y * m_camera->width() + x) * 3 + k];
-        color = aces_tone_map(color);
-        color = std::pow(color, 1.0 / 2.2);  // gamma_correction, src/util.h:131-134
-        pixel[k] = map_pixel(color);
-      }
-      output.set_pixel(x, y, pixel);
-    }
-  }
+  for (int y = 0; y < m_camera->height(); y++)
+    for (int x = 0; x < m_camera->width(); x++)
+      output.set_pixel(x, y, &rgb8[((size_t)y * m_camera->width() + x) * 3]);
   output.write(path);
 
   auto now = std::chrono::system_clock::now();

@@ -83,7 +83,7 @@ assert HIT_DTYPE.itemsize == 52
 
 # every symbol include/ptk.h declares
 EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "ptk_scene_info_get", "ptk_set_camera",
-           "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_read_accum", "ptk_synchronize",
+           "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_read_accum", "ptk_read_display_u8", "ptk_synchronize",
            "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream"]
 
 
@@ -179,6 +179,7 @@ def load_library():
     L.ptk_reset_accum.argtypes = [vp]
     L.ptk_render.argtypes = [vp, C.POINTER(PtkRenderParams)]
     L.ptk_read_accum.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    L.ptk_read_display_u8.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.ptk_synchronize.argtypes = [vp]
     L.ptk_intersect_batch.argtypes = [vp, vp, C.c_int32, vp]
     L.ptk_intersect_batch_device.argtypes = [vp, vp, C.c_int32, vp]
@@ -254,6 +255,13 @@ class Context:
         out = np.zeros((self.height, self.width, 3), np.float32)
         total = C.c_int32(0)
         self._check(self._L.ptk_read_accum(self.h, out.ctypes.data, C.byref(total)), "ptk_read_accum")
+        return out, int(total.value)
+
+    def read_display_u8(self):
+        """Renderer::save_image's tone-mapped 8-bit image (src/renderer.cpp:180-192), computed on the device."""
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        total = C.c_int32(0)
+        self._check(self._L.ptk_read_display_u8(self.h, out.ctypes.data, C.byref(total)), "ptk_read_display_u8")
         return out, int(total.value)
 
     def intersect(self, rays):

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "ptk.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ptk_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ptk_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -16,7 +16,7 @@ import pytest
 from oracle import orc
 from pathtracer_amd import native
 from tests import parity
-from tests.backends import BACKENDS, make_backend, scene
+from tests.backends import BACKENDS, GpuBackend, make_backend, scene
 
 CASES = [
     # scene, samples, max_bounce
@@ -133,3 +133,21 @@ def test_zero_work(backend, request):
     assert not img.any() and cnt["segments"] == 0
     img, cnt = b.render(4, 0, seed=1)  # max_bounce 0: trace_ray returns black at once (src/renderer.cpp:59-61)
     assert not img.any() and cnt["segments"] == 0 and cnt["camera_rays"] == 4 * sd.camera.width * sd.camera.height
+
+
+@pytest.mark.gpu
+def test_display_bytes_match_the_reference_post_process(gpu_ctx):
+    """ptk_read_display_u8 = Renderer::save_image's per-pixel loop (src/renderer.cpp:174-192) applied to the
+    buffer ptk_read_accum returns: the oracle's restatement of that loop gives the same bytes (a value within
+    1e-13 of a byte boundary could differ by one level between two pow implementations; none may differ by more)."""
+    from oracle import orc
+    sd = scene("envmap")
+    b = GpuBackend(gpu_ctx, sd)
+    b.render(16, 3, seed=5)
+    mean, total = gpu_ctx.read_accum()
+    got, total8 = gpu_ctx.read_display_u8()
+    want = orc.tonemap_u8(mean.astype(np.float64))
+    assert total == total8 == 16
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+    assert got.max() > 100 and got.min() < 50  # a real image, not a constant

@@ -2,9 +2,14 @@
 #include "ptk_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace ptk {
 
@@ -50,71 +55,115 @@ constexpr int kBins = 16;
 constexpr float kTraversalCost = 1.0f;
 constexpr float kIntersectCost = 1.2f;
 
+// Binned surface-area-heuristic builder.  Subtrees are independent, so the two sides of a large
+// split are built by different threads; which thread builds what does not influence the tree (every
+// decision depends only on the primitives of the range), and the flattening below numbers nodes by
+// a depth-first walk, so the result is identical for any thread count.
 struct Builder {
-  const std::vector<Box>& boxes;
-  std::vector<float> centroid;  // 3 per primitive
-  std::vector<int32_t> index;
-  std::vector<BuildNode> nodes;
-  int max_depth = 0, max_leaf = 0;
+  // A primitive as the builder moves it around: partitioning reorders these records themselves, so
+  // every pass over a range streams through memory instead of chasing indices.
+  struct Item {
+    Box box;
+    float centroid[3];
+    int32_t id;
+  };
+  std::vector<Item> items;
+  std::vector<BuildNode> nodes;  // sized for the worst case up front so that threads never reallocate it
+  std::atomic<int32_t> n_nodes{0};
+  std::atomic<int> max_depth{0}, max_leaf{0};
+  static constexpr int kParallelMin = 16384;  // smaller sides are not worth a thread
 
-  explicit Builder(const std::vector<Box>& b) : boxes(b)
+  explicit Builder(const std::vector<Box>& b)
   {
     size_t n = b.size();
-    centroid.resize(3 * n);
-    index.resize(n);
+    items.resize(n);
     for (size_t i = 0; i < n; i++) {
-      index[i] = (int32_t)i;
-      for (int a = 0; a < 3; a++) centroid[3 * i + a] = 0.5f * (b[i].lo[a] + b[i].hi[a]);
+      items[i].box = b[i];
+      items[i].id = (int32_t)i;
+      for (int a = 0; a < 3; a++) items[i].centroid[a] = 0.5f * (b[i].lo[a] + b[i].hi[a]);
     }
-    nodes.reserve(2 * n + 1);
+    nodes.resize(2 * n + 64);  // blocks of 2 * count per single-thread subtree + the few nodes above them
   }
 
-  int32_t build(int first, int count, int depth)
+  static void raise(std::atomic<int>& m, int v)
   {
-    int32_t ni = (int32_t)nodes.size();
-    nodes.emplace_back();
+    int cur = m.load(std::memory_order_relaxed);
+    while (cur < v && !m.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+  }
+
+  static int bin_of(const Item& it, int axis, float lo, float scale)
+  {
+    return std::min(kBins - 1, std::max(0, (int)((it.centroid[axis] - lo) * scale)));
+  }
+
+  void finish() { nodes.resize(std::min(nodes.size(), (size_t)n_nodes.load())); }  // slots are not dense: walk by links
+
+  // Node slots of a subtree built by one thread: a contiguous block taken from the shared counter once,
+  // so that threads do not write to each other's cache lines.
+  struct Block {
+    int32_t next, end;
+  };
+
+  int32_t build(int first, int count, int depth, int threads, Block* block = nullptr)
+  {
+    Block own;
+    if (!block && threads <= 1) {  // from here down this thread works alone: at most 2 * count - 1 nodes
+      own.next = n_nodes.fetch_add(2 * count);
+      own.end = own.next + 2 * count;
+      block = &own;
+    }
+    int32_t ni = block ? block->next++ : n_nodes.fetch_add(1);
     Box box, cbox;
     box.reset(); cbox.reset();
     for (int i = first; i < first + count; i++) {
-      box.grow(boxes[index[i]]);
-      cbox.grow(&centroid[3 * (size_t)index[i]]);
+      box.grow(items[i].box);
+      cbox.grow(items[i].centroid);
     }
     nodes[ni].box = box;
     nodes[ni].first = first;
     nodes[ni].count = count;
-    max_depth = std::max(max_depth, depth);
+    raise(max_depth, depth);
 
-    // --- choose a split ------------------------------------------------------
+    // --- choose a split: one pass bins the range along all three axes -----------
     int best_axis = -1, best_bin = -1;
     float best_cost = std::numeric_limits<float>::max();
     float parent_area = box.half_area();
     if (count > 1 && parent_area > 0.f) {
+      Box bin_box[3][kBins];
+      int bin_count[3][kBins];
+      float lo[3], scale[3];
+      bool use[3];
       for (int axis = 0; axis < 3; axis++) {
-        float lo = cbox.lo[axis], ext = cbox.hi[axis] - cbox.lo[axis];
-        if (!(ext > 0.f)) continue;
-        Box bin_box[kBins];
-        int bin_count[kBins];
-        for (int b = 0; b < kBins; b++) { bin_box[b].reset(); bin_count[b] = 0; }
-        float scale = (float)kBins / ext;
-        for (int i = first; i < first + count; i++) {
-          int p = index[i];
-          int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * (size_t)p + axis] - lo) * scale)));
-          bin_box[b].grow(boxes[p]);
-          bin_count[b]++;
+        float ext = cbox.hi[axis] - cbox.lo[axis];
+        lo[axis] = cbox.lo[axis];
+        use[axis] = ext > 0.f;
+        scale[axis] = use[axis] ? (float)kBins / ext : 0.f;
+        for (int b = 0; b < kBins; b++) { bin_box[axis][b].reset(); bin_count[axis][b] = 0; }
+      }
+      for (int i = first; i < first + count; i++) {
+        const Item& it = items[i];
+        for (int axis = 0; axis < 3; axis++) {
+          if (!use[axis]) continue;
+          int b = bin_of(it, axis, lo[axis], scale[axis]);
+          bin_box[axis][b].grow(it.box);
+          bin_count[axis][b]++;
         }
+      }
+      for (int axis = 0; axis < 3; axis++) {
+        if (!use[axis]) continue;
         float right_area[kBins];
         int right_count[kBins];
         Box acc;
         acc.reset();
         int c = 0;
         for (int b = kBins - 1; b > 0; b--) {
-          acc.grow(bin_box[b]); c += bin_count[b];
+          acc.grow(bin_box[axis][b]); c += bin_count[axis][b];
           right_area[b] = acc.half_area(); right_count[b] = c;
         }
         acc.reset();
         c = 0;
         for (int b = 0; b < kBins - 1; b++) {
-          acc.grow(bin_box[b]); c += bin_count[b];
+          acc.grow(bin_box[axis][b]); c += bin_count[axis][b];
           if (c == 0 || right_count[b + 1] == 0) continue;
           float cost = kTraversalCost +
                        kIntersectCost * (acc.half_area() * (float)c + right_area[b + 1] * (float)right_count[b + 1]) /
@@ -126,18 +175,15 @@ struct Builder {
     bool must_split = count > kMaxLeafSize;
     bool want_split = best_axis >= 0 && best_cost < kIntersectCost * (float)count;
     if (!must_split && (!want_split || depth + 1 > kMaxTreeDepth)) {
-      max_leaf = std::max(max_leaf, count);
+      raise(max_leaf, count);
       return ni;
     }
 
     int mid = -1;
     if (best_axis >= 0) {
       float lo = cbox.lo[best_axis], scale = (float)kBins / (cbox.hi[best_axis] - cbox.lo[best_axis]);
-      auto* begin = index.data() + first;
-      auto* m = std::partition(begin, begin + count, [&](int32_t p) {
-        int b = std::min(kBins - 1, std::max(0, (int)((centroid[3 * (size_t)p + best_axis] - lo) * scale)));
-        return b <= best_bin;
-      });
+      auto* begin = items.data() + first;
+      auto* m = std::partition(begin, begin + count, [&](const Item& it) { return bin_of(it, best_axis, lo, scale) <= best_bin; });
       mid = first + (int)(m - begin);
       int big = std::max(mid - first, first + count - mid);
       // Depth guard: an unbalanced split is only taken if the larger side can still be finished
@@ -150,14 +196,25 @@ struct Builder {
       if (e1 > e0 && e1 >= e2) axis = 1;
       else if (e2 > e0 && e2 > e1) axis = 2;
       mid = first + (count + 1) / 2;
-      auto* begin = index.data() + first;
-      std::nth_element(begin, begin + (mid - first), begin + count, [&](int32_t a, int32_t b) {
-        float ca = centroid[3 * (size_t)a + axis], cb = centroid[3 * (size_t)b + axis];
-        return ca < cb || (ca == cb && a < b);
+      auto* begin = items.data() + first;
+      std::nth_element(begin, begin + (mid - first), begin + count, [&](const Item& a, const Item& b) {
+        float ca = a.centroid[axis], cb = b.centroid[axis];
+        return ca < cb || (ca == cb && a.id < b.id);
       });
     }
-    int32_t l = build(first, mid - first, depth + 1);
-    int32_t r = build(mid, first + count - mid, depth + 1);
+    const int nl = mid - first, nr = first + count - mid;
+    int32_t l, r;
+    if (threads > 1 && std::min(nl, nr) >= kParallelMin) {
+      int tl = (int)((int64_t)threads * nl / count);
+      tl = std::min(std::max(tl, 1), threads - 1);
+      std::thread left([&, tl] { l = build(first, nl, depth + 1, tl); });
+      r = build(mid, nr, depth + 1, threads - tl);
+      left.join();
+    } else {
+      // a lopsided split keeps the whole thread budget on its large side
+      l = build(first, nl, depth + 1, nl >= nr ? threads : 1, block);
+      r = build(mid, nr, depth + 1, nr > nl ? threads : 1, block);
+    }
     nodes[ni].left = l;
     nodes[ni].right = r;
     return ni;
@@ -359,11 +416,25 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
     out.prims.assign(1, by_id[0]);
     return std::string();
   }
+  const bool timing = getenv("PTK_BUILD_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ptk build] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
   Builder bld(boxes);
-  bld.build(0, n, 0);
+  lap("centroids");
+  // 16 = one GPU's share of a node's host cores (std::thread::hardware_concurrency() sees the whole node)
+  int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("PTK_BUILD_THREADS")) threads = std::max(1, atoi(e));
+  bld.build(0, n, 0, threads);
+  bld.finish();
+  lap("tree");
   out.max_depth = bld.max_depth;
   out.max_leaf = bld.max_leaf;
-  if (bld.max_depth > kMaxTreeDepth) return "internal: BVH deeper than the traversal stack allows";
+  if (out.max_depth > kMaxTreeDepth) return "internal: BVH deeper than the traversal stack allows";
 
   // Flatten.  Leaves take their primitives in depth-first order; an inner build node becomes
   // one NodePair carrying both children's boxes.
@@ -378,7 +449,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
       const BuildNode& bn = bld.nodes[b];
       if (bn.left < 0) {
         leaf_first[b] = (int32_t)out.prims.size();
-        for (int i = bn.first; i < bn.first + bn.count; i++) out.prims.push_back(by_id[bld.index[i]]);
+        for (int i = bn.first; i < bn.first + bn.count; i++) out.prims.push_back(by_id[bld.items[i].id]);
       } else {
         stack.push_back(bn.right);
         stack.push_back(bn.left);
@@ -423,6 +494,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
     np.child0 = c0; np.child1 = c1;
     for (auto r = mine.rbegin(); r != mine.rend(); ++r) todo.push_back(*r);
   }
+  lap("flatten");
   return std::string();
 }
 

@@ -28,8 +28,8 @@ constexpr int kBlock = 64;  // one wave per workgroup: a finished wave frees its
 constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 
 // Wave scheduling knobs of the render kernel (see its main loop).  Measured on the 81,920-triangle
-// mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: same,
-// 24: -4%, 32: -6%; lit 16: -9%, 4: -1%; shade 32: -9%, 16: -4%; item 16: -9%, 1: -6%; 3 waves
+// mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: -7%,
+// 24: -2%; lit 16: -9%, 4: -1%; shade 32: -9%, 16: -4%; item 16: -9%, 1: -6%; 3 waves
 // per SIMD: same, 5 (96 VGPRs, spills): -4%.
 #ifndef PTK_DESCEND_MIN
 #define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
 
   // Every lane keeps one query in flight.  The wave alternates uniform phases, each run only when
   // enough lanes want it (or when no lane is traversing any more, so that everything drains):
-  //   descend  - lanes at an inner node visit it, repeated while at least kDescendMin lanes are at one;
-  //   leaves   - lanes at a leaf intersect its primitives (the few lanes still at an inner node take
-  //              one more step beside them);
+  //   descend  - lanes at an inner node visit it, repeated while at least kDescendMin lanes are at one
+  //              (or while no lane is at a leaf);
+  //   leaves   - lanes at a leaf intersect its primitives;
   //   lit      - lanes whose shadow ray has finished add the light and start the path's next segment;
   //   shade    - lanes whose path segment has finished shade the hit and start a shadow ray or the
   //              next segment;
@@ -212,13 +212,13 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     for (;;) {
       bool want = trav_at_inner(ps.tr);
       int n_want = __popcll(__ballot(want));
-      if (n_want < kDescendMin) break;
+      // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no lane is at a leaf
+      if (n_want == 0 || (n_want < kDescendMin && __ballot(trav_at_leaf(ps.tr)) != 0ull)) break;
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(trav_at_leaf(ps.tr))); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
     if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
-    else if (kDescendMin > 1 && trav_at_inner(ps.tr)) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     const bool done = trav_done(ps.tr);
     const bool waiting = ps.alive && done && !need;
     const bool lit = waiting && ps.shadow, shade = waiting && !ps.shadow;

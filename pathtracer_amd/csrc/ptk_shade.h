@@ -373,7 +373,7 @@ PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, con
 // the visibility query is evaluated here; the result waits in ps.pending until the shadow ray returns.
 // Returns false when no shadow ray is needed.
 PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s,
-                      v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out)
+                      v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out, float& t_stop_out)
 {
   if (sc.n_lights == 0) return false;
   int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
@@ -421,6 +421,10 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   ps.light_id = light.id;
   to_light_out = to_light;
   distance_out = distance;
+  // A flat light is met by this ray at `distance` and nowhere else, so any other primitive hit clearly
+  // before that decides the query (the light is not the closest hit) and the traversal may stop there.
+  // A sphere light can be met before the sampled point, so its shadow rays run to the end.
+  t_stop_out = light.kind == kTriangle ? distance * 0.999f - 1e-3f : -1.0f;
   return true;
 }
 
@@ -464,13 +468,14 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   ps.origin_id = s.id;
   ps.tr.o = s.point;
   v3 to_light;
-  float distance;
-  if (fl.direct_light_sampling && !specular && nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance)) {
+  float distance, t_stop;
+  if (fl.direct_light_sampling && !specular &&
+      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop)) {
     ps.shadow = true;
     ps.next_d = next_d;
     cnt.queries++;
     // the light is at `distance`: nothing farther can be the closest hit that counts
-    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id);
+    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, ps.light_id, t_stop);
     return false;
   }
   return path_next_segment(ps, st, sc, pp, fl, next_d, cnt);

@@ -120,6 +120,11 @@ struct Traversal {
   Hit hit;
   int32_t node;      // >= 0 inner node, kTravDone finished, other negative values: leaf
   uint32_t skip_id;  // primitive the ray starts on (kNoPrim for none)
+  // Visibility queries: the caller only asks whether `target` is the closest hit.  A hit on any other
+  // primitive nearer than t_stop answers that (no), so the traversal ends there.  t_stop < 0: a plain
+  // closest-hit query.
+  uint32_t target;
+  float t_stop;
 };
 
 PTK_HD bool trav_done(const Traversal& tr) { return tr.node == kTravDone; }
@@ -127,8 +132,11 @@ PTK_HD bool trav_at_inner(const Traversal& tr) { return tr.node >= 0; }
 PTK_HD bool trav_at_leaf(const Traversal& tr) { return tr.node < 0 && tr.node != kTravDone; }
 
 template <class Stack>
-PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id)
+PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id,
+                       uint32_t target = kNoPrim, float t_stop = -1.0f)
 {
+  tr.target = target;
+  tr.t_stop = t_stop;
   tr.o = o; tr.d = d;
   // 1/d is kept finite: with an infinite 1/d the fused form below would turn "inf - inf" into NaN for one
   // plane of a slab that contains the origin.  1e20 keeps every product far inside the float range.
@@ -205,7 +213,9 @@ PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& c
     trav_test_prim<STATS>(tr, p, cnt);
     p = next;
   }
-  tr.node = (int32_t)st.pop();
+  const int32_t next_node = (int32_t)st.pop();
+  const bool decided = (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);  // see Traversal::t_stop
+  tr.node = decided ? kTravDone : next_node;
 }
 
 // One whole query on one lane (used where rays are independent: the ray-batch entry point).

@@ -56,6 +56,12 @@ def _near_parallel(sd, ids, dirs):
     return out
 
 
+def _max_rel_t(rt, gt, t_floor, sel):
+    if not sel.any():
+        return 0.0
+    return float((np.maximum(np.abs(rt - gt) - t_floor, 0.0)[sel] / np.maximum(rt[sel], 1e-30)).max())
+
+
 def classify_hits(sd, rays, ref, got):
     """Returns dict of counts; 'unexplained' must be 0."""
     rays = np.asarray(rays, np.float64).reshape(-1, 6)
@@ -82,7 +88,7 @@ def classify_hits(sd, rays, ref, got):
     res = dict(n=n, ok=int(ok.sum()), cond=int(cond.sum()), tie=0, near=0, ref_miss=0, graze=0, unexplained=0)
     bad = np.nonzero(~ok)[0]
     if len(bad) == 0:
-        res["max_rel_t"] = float((np.maximum(np.abs(rt - gt) - t_floor, 0.0)[same] / np.maximum(rt[same], 1e-30)).max()) if same.any() else 0.0
+        res["max_rel_t"] = _max_rel_t(rt, gt, t_floor, same & ~cond)  # grazing hits are counted in "cond" instead
         return res
     o, d = rays[bad, :3], rays[bad, 3:]
     b_rh, b_gh, b_rt, b_gt = rh[bad], gh[bad], rt[bad], gt[bad]
@@ -108,7 +114,7 @@ def classify_hits(sd, rays, ref, got):
     res["graze"] = int((graze & rest).sum())
     res["unexplained"] = int((rest & ~graze).sum())
     res["unexplained_idx"] = bad[rest & ~graze][:10].tolist()
-    res["max_rel_t"] = float((np.maximum(np.abs(rt - gt) - t_floor, 0.0)[same] / np.maximum(rt[same], 1e-30)).max()) if same.any() else 0.0
+    res["max_rel_t"] = _max_rel_t(rt, gt, t_floor, same & ~cond)  # grazing hits are counted in "cond" instead
     return res
 
 

@@ -117,7 +117,8 @@ def main():
         torch.cuda.synchronize()  # the kernel runs on the library's own stream
         for c in plan:
             ctx.render(c.samples, ARGS.bounces, seed=ARGS.seed + step, sample_first=c.sample_first,
-                       sample_stride=c.sample_stride, row_begin=c.row_begin, row_end=c.row_end)
+                       sample_stride=c.sample_stride, row_begin=c.row_begin, row_end=c.row_end,
+                       band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
         ctx.synchronize()
         parallel.reduce_frame(accum, world)  # RCCL over xGMI: the frame's one exchange step
 

@@ -103,7 +103,10 @@ typedef struct {
  * Sample indices are global: this call renders indices sample_first + k*sample_stride,
  * k = 0..samples-1, of every pixel in rows [row_begin, row_end).  Splitting a frame by
  * sample index (stride = number of GPUs) or by rows gives the same sample set as one
- * call on one GPU. */
+ * call on one GPU.  Rows can also be shared in interleaved bands: with band_rows > 0 the call
+ * renders, of the bands of band_rows rows that the image divides into (band b = rows
+ * [b*band_rows, (b+1)*band_rows)), the bands band_first, band_first + band_stride, ... in ONE
+ * launch; row_begin / row_end must then be 0. */
 typedef struct {
   int32_t samples;
   int32_t max_bounce;     /* Renderer::m_max_bounce */
@@ -113,6 +116,9 @@ typedef struct {
   int32_t row_begin;      /* 0 */
   int32_t row_end;        /* <= 0 means height */
   int32_t collect_stats;  /* 1: also count box / primitive tests (slower kernel variant) */
+  int32_t band_rows;      /* 0: rows [row_begin, row_end); else a multiple of 8 */
+  int32_t band_first;     /* >= 0 */
+  int32_t band_stride;    /* >= 1 when band_rows > 0 */
 } ptk_render_params;
 
 /* Ray, src/ray.h:5-9 */

@@ -105,7 +105,19 @@ struct RenderArgs {
   int32_t row_begin, row_end;
   int32_t tiles_x, n_tiles;
   int32_t chunks;  // workgroups per tile; each takes every chunks-th sample
+  // Rows of the launch -> rows of the image.  A launch covers `rows` rows (a multiple of the tile
+  // height, the image edge is cut off by row_end): either rows [row_begin, row_end) of the image, or
+  // the interleaved bands band_first, band_first + band_stride, ... of band_rows rows each.
+  int32_t rows;
+  int32_t band_rows, band_first, band_stride;  // band_rows == 0: no bands
 };
+
+__host__ __device__ __forceinline__ int launch_row_to_image_row(const RenderArgs& ra, int r)
+{
+  if (ra.band_rows == 0) return ra.row_begin + r;
+  int j = r / ra.band_rows;
+  return (ra.band_first + j * ra.band_stride) * ra.band_rows + (r - j * ra.band_rows);
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin, so ids b and b+8 share an L2.  Give each
 // residue class a contiguous run of tiles.  Bijective for any grid size.
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
 
   Counters cnt = {0, 0, 0, 0, 0};
   PathParams pp;
-  pp.x0 = tx * kTile; pp.y0 = ra.row_begin + ty * kTile;
+  pp.x0 = tx * kTile; pp.y0 = launch_row_to_image_row(ra, ty * kTile);
   pp.slot_bits = 6; pp.row_bits = 3;
   pp.x_end = cam.width; pp.y_end = ra.row_end;
   pp.max_bounce = ra.max_bounce; pp.seed = ra.seed;
@@ -250,27 +262,33 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
       accum[i] = b;
     } else {
-      size_t rows = (size_t)(ra.row_end - ra.row_begin);
-      size_t i = ((size_t)chunk * rows + (size_t)(py - ra.row_begin)) * (size_t)cam.width + (size_t)px;
+      // partial sums are indexed by the launch's own rows
+      size_t r = (size_t)(ty * kTile + (lane >> 3));
+      size_t i = ((size_t)chunk * (size_t)ra.rows + r) * (size_t)cam.width + (size_t)px;
       partial[i] = a;
     }
   }
   flush_counters(cnt, counters);
 }
 
-// accum[row_begin .. row_end) += partial[0] + partial[1] + ... in that order (one fixed summation
+// accum[rows of the launch] += partial[0] + partial[1] + ... in that order (one fixed summation
 // order, so a frame does not depend on which workgroup finished first).
 __global__ __launch_bounds__(256) void fold_partials_kernel(f4* __restrict__ accum, const f4* __restrict__ partial,
-                                                            size_t first, size_t count, int chunks)
+                                                            RenderArgs ra, int width)
 {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t count = (size_t)ra.rows * (size_t)width;
   if (i >= count) return;
-  f4 a = accum[first + i];
-  for (int c = 0; c < chunks; c++) {
+  int r = (int)(i / (size_t)width), x = (int)(i - (size_t)r * (size_t)width);
+  int y = launch_row_to_image_row(ra, r);
+  if (y >= ra.row_end) return;
+  size_t o = (size_t)y * (size_t)width + (size_t)x;
+  f4 a = accum[o];
+  for (int c = 0; c < ra.chunks; c++) {
     f4 p = partial[(size_t)c * count + i];
     a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
   }
-  accum[first + i] = a;
+  accum[o] = a;
 }
 
 template <bool STATS>
@@ -617,19 +635,31 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
   ra.row_end = p->row_end <= 0 ? ctx->cam.height : p->row_end;
   if (ra.row_begin < 0 || ra.row_end > ctx->cam.height || ra.row_begin > ra.row_end)
     return fail(ctx, PTK_ERR_INVALID, "ptk_render: row range outside the image");
-  if (p->samples == 0 || ra.row_begin == ra.row_end) return PTK_OK;
+  ra.band_rows = 0; ra.band_first = 0; ra.band_stride = 1;
+  int launch_rows = ra.row_end - ra.row_begin;
+  if (p->band_rows != 0) {
+    if (p->band_rows < 0 || p->band_rows % kTile != 0 || p->band_first < 0 || p->band_stride < 1)
+      return fail(ctx, PTK_ERR_INVALID, "ptk_render: band_rows must be a positive multiple of 8, band_first >= 0, band_stride >= 1");
+    if (ra.row_begin != 0 || ra.row_end != ctx->cam.height)
+      return fail(ctx, PTK_ERR_INVALID, "ptk_render: interleaved bands cover the whole image: leave row_begin and row_end 0");
+    const int n_bands = (ctx->cam.height + p->band_rows - 1) / p->band_rows;
+    const int mine = p->band_first < n_bands ? (n_bands - p->band_first + p->band_stride - 1) / p->band_stride : 0;
+    ra.band_rows = p->band_rows; ra.band_first = p->band_first; ra.band_stride = p->band_stride;
+    launch_rows = mine * p->band_rows;
+  }
+  if (p->samples == 0 || launch_rows == 0) return PTK_OK;
   ra.tiles_x = (ctx->cam.width + kTile - 1) / kTile;
-  int tiles_y = (ra.row_end - ra.row_begin + kTile - 1) / kTile;
+  int tiles_y = (launch_rows + kTile - 1) / kTile;
+  ra.rows = tiles_y * kTile;
   ra.n_tiles = ra.tiles_x * tiles_y;
   ra.chunks = pick_chunks(ra.n_tiles, p->samples);
   PTK_HIP(hipSetDevice(ctx->device));
-  size_t band_pixels = (size_t)(ra.row_end - ra.row_begin) * (size_t)ctx->cam.width;
+  size_t band_pixels = (size_t)ra.rows * (size_t)ctx->cam.width;
   if (ra.chunks > 1) {
     size_t need = band_pixels * (size_t)ra.chunks;
     if (need > ctx->partial_capacity) {
       PTK_HIP(hipStreamSynchronize(ctx->stream));  // an earlier frame may still be folding the old buffer
       if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-  if (ctx->d_display) (void)hipFree(ctx->d_display);
       ctx->d_partial = nullptr;
       ctx->partial_capacity = 0;
       PTK_HIP(hipMalloc((void**)&ctx->d_partial, need * sizeof(f4)));
@@ -650,9 +680,8 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
   rc = end_timed(ctx, ev);
   if (rc) return rc;
   if (ra.chunks > 1) {
-    size_t first = (size_t)ra.row_begin * (size_t)ctx->cam.width;
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((band_pixels + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum,
-                       ctx->d_partial, first, band_pixels, ra.chunks);
+                       ctx->d_partial, ra, ctx->cam.width);
     PTK_HIP(hipGetLastError());
   }
   return PTK_OK;

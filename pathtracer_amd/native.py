@@ -55,7 +55,8 @@ class PtkFlags(C.Structure):
 class PtkRenderParams(C.Structure):
     _fields_ = [("samples", C.c_int32), ("max_bounce", C.c_int32), ("seed", C.c_uint32), ("sample_first", C.c_int32),
                 ("sample_stride", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-                ("collect_stats", C.c_int32)]
+                ("collect_stats", C.c_int32), ("band_rows", C.c_int32), ("band_first", C.c_int32),
+                ("band_stride", C.c_int32)]
 
 
 class PtkStats(C.Structure):
@@ -243,9 +244,10 @@ class Context:
         self._check(self._L.ptk_reset_accum(self.h), "ptk_reset_accum")
 
     def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, row_begin=0, row_end=0,
-               collect_stats=False):
+               collect_stats=False, band_rows=0, band_first=0, band_stride=1):
         p = PtkRenderParams(int(samples), int(max_bounce), int(seed), int(sample_first), int(sample_stride),
-                            int(row_begin), int(row_end), 1 if collect_stats else 0)
+                            int(row_begin), int(row_end), 1 if collect_stats else 0, int(band_rows), int(band_first),
+                            int(band_stride))
         self._check(self._L.ptk_render(self.h, C.byref(p)), "ptk_render")
 
     def synchronize(self):

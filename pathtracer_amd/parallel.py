@@ -9,7 +9,8 @@ Two ways to shard, both with GLOBAL sample indices so that the union over ranks 
 single GPU would render:
 
   "spp"   rank r renders sample indices r, r + world, r + 2*world, ... of every pixel;
-  "tile"  rank r renders all samples of the 16-row bands b with b % world == r (interleaved for balance).
+  "tile"  rank r renders all samples of the 16-row bands b with b % world == r (interleaved for balance),
+          all of them in one launch per batch.
 
 The accumulation buffer holds (sum r, sum g, sum b, sample count) per pixel, so a SUM reduce merges either
 kind of shard: disjoint bands add zeros, interleaved samples add partial sums and counts.
@@ -29,6 +30,16 @@ class RenderCall:
     sample_stride: int
     row_begin: int
     row_end: int
+    band_rows: int = 0    # > 0: the interleaved bands band_first, band_first + band_stride, ... of this many rows
+    band_first: int = 0
+    band_stride: int = 1
+
+    def rows(self, height: int):
+        """The image rows this call renders."""
+        if self.band_rows <= 0:
+            return range(self.row_begin, self.row_end if self.row_end > 0 else height)
+        return [y for y in range(height)
+                if y // self.band_rows >= self.band_first and (y // self.band_rows - self.band_first) % self.band_stride == 0]
 
 
 def frame_plan(split: str, rank: int, world: int, samples_per_rank: int, height: int, sample_base: int = 0,
@@ -55,9 +66,9 @@ def frame_plan(split: str, rank: int, world: int, samples_per_rank: int, height:
             calls.append(RenderCall(n, sample_base + rank + done * world, world, 0, height))
     else:
         n_bands = (height + BAND_ROWS - 1) // BAND_ROWS
-        for b in range(rank, n_bands, world):
+        if rank < n_bands:
             for done, n in chunks:
-                calls.append(RenderCall(n, sample_base + done, 1, b * BAND_ROWS, min(height, (b + 1) * BAND_ROWS)))
+                calls.append(RenderCall(n, sample_base + done, 1, 0, 0, BAND_ROWS, rank, world))
     return calls
 
 

@@ -33,12 +33,13 @@ class GpuBackend:
         return hits, dict(box_tests=s["box_tests"], prim_tests=s["prim_tests"])
 
     def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, row_begin=0, row_end=0, flags=None,
-               reset=True, collect_stats=True):
+               reset=True, collect_stats=True, band_rows=0, band_first=0, band_stride=1):
         self.ctx.set_flags(flags if flags is not None else native.PtkFlags.defaults())
         if reset:
             self.ctx.reset_accum()
         self.ctx.reset_stats()
-        self.ctx.render(samples, max_bounce, seed, sample_first, sample_stride, row_begin, row_end, collect_stats)
+        self.ctx.render(samples, max_bounce, seed, sample_first, sample_stride, row_begin, row_end, collect_stats,
+                        band_rows, band_first, band_stride)
         img, total = self.ctx.read_accum()
         s = self.ctx.stats()
         return img.astype(np.float64), {k: s[k] for k in ("camera_rays", "segments", "queries", "box_tests", "prim_tests")}
@@ -58,11 +59,11 @@ class HostBackend:
         return self.k.intersect(rays)
 
     def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, row_begin=0, row_end=0, flags=None,
-               reset=True, collect_stats=True):
+               reset=True, collect_stats=True, band_rows=0, band_first=0, band_stride=1):
         if reset or self.accum is None:
             self.accum = None
         self.accum, cnt = self.k.render(samples, max_bounce, seed, sample_first, sample_stride, row_begin, row_end,
-                                        flags, self.accum)
+                                        flags, self.accum, band_rows, band_first, band_stride)
         w = self.accum[..., 3:4]
         img = np.where(w > 0, self.accum[..., :3] / np.maximum(w, 1e-30), 0.0)
         return img.astype(np.float64), cnt

@@ -80,11 +80,12 @@ class HostCheck:
         return hits, dict(box_tests=int(cnt[0]), prim_tests=int(cnt[1]), stack_high_water=int(high))
 
     def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, row_begin=0, row_end=0,
-               flags=None, accum=None):
+               flags=None, accum=None, band_rows=0, band_first=0, band_stride=1):
         w, h = self.cam.width, self.cam.height
         if accum is None:
             accum = np.zeros((h, w, 4), np.float32)
-        p = native.PtkRenderParams(samples, max_bounce, seed, sample_first, sample_stride, row_begin, row_end, 1)
+        p = native.PtkRenderParams(samples, max_bounce, seed, sample_first, sample_stride, row_begin, row_end, 1,
+                                   band_rows, band_first, band_stride)
         fl = flags if flags is not None else native.PtkFlags.defaults()
         cnt = np.zeros(5, np.uint64)
         lib().hc_render(self.h, C.byref(self.cam), C.byref(fl), C.byref(p), accum.ctypes.data, cnt.ctypes.data)

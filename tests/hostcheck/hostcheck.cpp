@@ -107,6 +107,10 @@ void hc_render(void* h, const ptk_camera* camera, const ptk_flags* flags, const 
     uint64_t loc[5] = {0, 0, 0, 0, 0};
 #pragma omp for schedule(dynamic, 1)
     for (int y = p->row_begin; y < row_end; y++) {
+      if (p->band_rows > 0) {  // interleaved bands: only those of this call
+        int b = y / p->band_rows - p->band_first;
+        if (b < 0 || b % p->band_stride != 0) continue;
+      }
       for (int x = 0; x < cam.width; x++) {
         HostStack st;
         Counters cnt = {0, 0, 0, 0, 0};

@@ -33,7 +33,8 @@ def _worker(rank, world, port, split, spp, bounces, out_path):
     accum = np.zeros((40, 40, 4), np.float32)
     for c in parallel.frame_plan(split, rank, world, spp, 40, batch=3):
         k.render(c.samples, bounces, seed=4, sample_first=c.sample_first, sample_stride=c.sample_stride,
-                 row_begin=c.row_begin, row_end=c.row_end, accum=accum)
+                 row_begin=c.row_begin, row_end=c.row_end, accum=accum,
+                 band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
     t = torch.from_numpy(accum)
     parallel.reduce_frame(t, world)
     if rank == 0:
@@ -61,7 +62,8 @@ def test_two_ranks_reproduce_the_single_process_frame(split, tmp_path):
         ref = np.zeros_like(single)
         for c in parallel.frame_plan("tile", 0, 1, spp, 40, batch=3):
             k.render(c.samples, bounces, seed=4, sample_first=c.sample_first, sample_stride=c.sample_stride,
-                     row_begin=c.row_begin, row_end=c.row_end, accum=ref)
+                     row_begin=c.row_begin, row_end=c.row_end, accum=ref,
+                     band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
         assert np.array_equal(merged, ref)
     assert np.allclose(merged[..., :3], single[..., :3], rtol=2e-5, atol=1e-5)
 
@@ -73,7 +75,7 @@ def test_frame_plan_covers_every_sample_once():
             seen = {}
             for rank in range(world):
                 for c in parallel.frame_plan(split, rank, world, spp, height, batch=4):
-                    for y in range(c.row_begin, c.row_end):
+                    for y in c.rows(height):
                         for s in range(c.samples):
                             key = (y, c.sample_first + s * c.sample_stride)
                             seen[key] = seen.get(key, 0) + 1

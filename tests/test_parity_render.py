@@ -123,6 +123,13 @@ def test_frame_splits_give_the_same_samples(backend, request):
     b.render(5, 3, seed=9, sample_first=0)
     batched, _ = b.render(3, 3, seed=9, sample_first=5, reset=False)
     assert np.allclose(batched, full, rtol=1e-5, atol=1e-6)
+    # interleaved bands of 8 rows, as three GPUs would share them (one launch each)
+    first, _ = b.render(8, 3, seed=9, band_rows=8, band_first=0, band_stride=3)
+    rows = np.arange(h)
+    assert first[(rows // 8) % 3 == 0].any() and not first[(rows // 8) % 3 != 0].any()
+    b.render(8, 3, seed=9, band_rows=8, band_first=1, band_stride=3, reset=False)
+    banded, cnt = b.render(8, 3, seed=9, band_rows=8, band_first=2, band_stride=3, reset=False)
+    assert np.allclose(banded, full, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

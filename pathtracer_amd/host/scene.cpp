@@ -85,6 +85,7 @@ void Scene::add_primitive(const Primitive& p)
 
 void Scene::add_primitives(const std::vector<Primitive>::iterator begin, const std::vector<Primitive>::iterator end)
 {
+  m_primitives.reserve(m_primitives.size() + (size_t)(end - begin));
   for (auto it = begin; it != end; it++) add_primitive(*it);
 }
 
@@ -137,6 +138,7 @@ std::vector<Primitive> Scene::load_obj(const std::filesystem::path& filename)
   Material* default_material = add_material(default_albedo);  // src/scene.cpp:215
 
   size_t triangle_count = mesh.vertices.size() / 3;
+  triangles.reserve(triangle_count);
   for (size_t i = 0; i < triangle_count; i++) {
     const pt::ObjVertex* v = &mesh.vertices[i * 3];
     Triangle tri;
@@ -179,6 +181,8 @@ void Scene::compute_bvh()
   // primitive ids must stay what add_primitive assigned; the C ABI numbers triangles first, then spheres,
   // which is the reference's own order (models before spheres, src/main.cpp:117-145)
   bool seen_sphere = false;
+  tri_pos.reserve(m_primitives.size() * 9); tri_nrm.reserve(m_primitives.size() * 9);
+  tri_uv.reserve(m_primitives.size() * 6); tri_mat.reserve(m_primitives.size());
   for (const Primitive& p : m_primitives) {
     int mat = (int)(p.material - &m_materials[0]);
     if (p.type == Primitive::TRIANGLE) {

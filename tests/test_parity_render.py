@@ -158,3 +158,23 @@ def test_display_bytes_match_the_reference_post_process(gpu_ctx):
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
     assert got.max() > 100 and got.min() < 50  # a real image, not a constant
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("width,height", [(37, 23), (8, 8), (1, 1), (5, 130)])
+def test_image_sizes_that_do_not_fill_tiles(backend, width, height, request):
+    """Widths and heights that are not multiples of the 8 x 8 tile, down to a single pixel; also as interleaved
+    bands whose last band is cut off by the image edge."""
+    from pathtracer_amd import scenes
+    sd = scenes.cornell_box(width, height)
+    o = orc.OracleScene(sd)
+    b = make_backend(backend, sd, request)
+    ref, cref = o.render(32, 3, seed=17)
+    got, cgot = b.render(32, 3, seed=17)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert cgot["camera_rays"] == cref["camera_rays"] == 32 * width * height
+    st = parity.image_stats(ref, got)
+    assert st["frac_diff"] <= 0.08 and st["mean_rel"] <= 0.02, st
+    b.render(32, 3, seed=17, band_rows=8, band_first=0, band_stride=2)
+    banded, _ = b.render(32, 3, seed=17, band_rows=8, band_first=1, band_stride=2, reset=False)
+    assert np.allclose(banded, got, rtol=1e-5, atol=1e-6)

@@ -11,8 +11,11 @@ namespace ptk {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
-constexpr int kStackDepth = 32;   // per-lane traversal stack entries; the builder keeps trees shallower
-constexpr int kMaxTreeDepth = 30;
+#ifndef PTK_STACK_DEPTH
+#define PTK_STACK_DEPTH 32
+#endif
+constexpr int kStackDepth = PTK_STACK_DEPTH;   // per-lane traversal stack entries; the builder keeps trees shallower
+constexpr int kMaxTreeDepth = kStackDepth - 2;
 
 // Inner node with the boxes of BOTH children (one 64-byte fetch decides both).
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first_prim << 3) | (count - 1).

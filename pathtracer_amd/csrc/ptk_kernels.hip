@@ -299,8 +299,9 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
   LdsStack st;
   st.base = st.top = lds_stack + threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
-  int i = (int)(blockIdx.x * kBlock + threadIdx.x);
-  if (i < n) {
+  // A wave takes batches of 64 consecutive rays, grid-stride: the grid is capped (launch_intersect) so that
+  // a large batch is not a quarter of a million one-shot workgroups each ending in counter atomics.
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const float* r = rays + 6 * (size_t)i;
     v3 o = V3(r[0], r[1], r[2]), d = V3(r[3], r[4], r[5]);
     Hit hit;
@@ -750,7 +751,7 @@ static int launch_intersect(ptk_ctx* ctx, const float* d_rays, int32_t n, ptk_hi
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc = begin_timed(ctx, ev);
   if (rc) return rc;
-  dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+  dim3 grid((unsigned)std::min<int64_t>(((int64_t)n + kBlock - 1) / kBlock, 16384)), block(kBlock);  // 4 rounds of the resident waves
   if (stats) hipLaunchKernelGGL(intersect_kernel<true>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
   else hipLaunchKernelGGL(intersect_kernel<false>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
   PTK_HIP(hipGetLastError());

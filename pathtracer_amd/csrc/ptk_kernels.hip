@@ -299,25 +299,61 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
   LdsStack st;
   st.base = st.top = lds_stack + threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
-  // A wave takes batches of 64 consecutive rays, grid-stride: the grid is capped (launch_intersect) so that
-  // a large batch is not a quarter of a million one-shot workgroups each ending in counter atomics.
-  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-    const float* r = rays + 6 * (size_t)i;
-    v3 o = V3(r[0], r[1], r[2]), d = V3(r[3], r[4], r[5]);
-    Hit hit;
-    cnt.queries++;
-    ptk_hit out;
-    memset(&out, 0, sizeof out);
-    if (closest_hit<LdsStack, STATS>(sc, o, d, kTMax, kNoPrim, st, hit, cnt)) {
-      Surface s;
-      make_surface(sc, o, d, hit, s);
-      out.hit = 1; out.id = hit.id; out.t = hit.t;
-      out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
-      out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
-      out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
-      out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
+  // A wave owns a contiguous run of the batch (the grid is capped by launch_intersect: a quarter of a million
+  // one-shot workgroups, each ending in counter atomics, cost ten times the traversal) and works through it
+  // like the render kernel works through a tile: lanes take the next rays as their queries finish, and the
+  // wave alternates descend / leaf / hand-over phases.
+  const long long per = (((long long)n + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock * kBlock;
+  long long next = (long long)blockIdx.x * per;  // wave-uniform
+  const long long end = next + per < (long long)n ? next + per : (long long)n;
+  Traversal tr;
+  tr.node = kTravDone;
+  tr.o = tr.d = V3(0.f, 0.f, 0.f);
+  long long mine = -1;  // the ray this lane is working on
+  bool alive = true;
+  for (;;) {
+    const bool done = trav_done(tr);
+    const bool need = alive && done;
+    const unsigned long long need_mask = __ballot(need);
+    const bool idle = __ballot(!done) == 0ull;
+    if (idle && need_mask == 0ull) break;
+    if (__popcll(need_mask) >= PTK_ITEM_MIN || idle) {
+      if (need && mine >= 0) {
+        ptk_hit out;
+        memset(&out, 0, sizeof out);
+        if (tr.hit.id != kNoPrim) {
+          Surface s;
+          make_surface(sc, tr.o, tr.d, tr.hit, s);
+          out.hit = 1; out.id = tr.hit.id; out.t = tr.hit.t;
+          out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
+          out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
+          out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
+          out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
+        }
+        hits[mine] = out;
+      }
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+      const long long take = next + rank;
+      next += __popcll(need_mask);
+      if (need) {
+        if (take < end) {
+          const float* r = rays + 6 * (size_t)take;
+          mine = take;
+          cnt.queries++;
+          trav_begin(tr, st, sc, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), kTMax, kNoPrim);
+        } else {
+          alive = false;
+          mine = -1;
+        }
+      }
     }
-    hits[i] = out;
+    for (;;) {
+      const bool want = trav_at_inner(tr);
+      const int n_want = __popcll(__ballot(want));
+      if (n_want == 0 || (n_want < kDescendMin && __ballot(trav_at_leaf(tr)) != 0ull)) break;
+      if (want) trav_inner<LdsStack, STATS>(tr, st, sc, cnt);
+    }
+    if (trav_at_leaf(tr)) trav_leaf<LdsStack, STATS>(tr, st, sc, cnt);
   }
   flush_counters(cnt, counters);
 }

@@ -413,12 +413,17 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
     normal = ((s.point + to_light * t) - ld3(light.p0)) * (1.0f / light.radius);
     if (dot(to_light, normal) > 0.0f) normal = -normal;
   }
-  Frame fr = make_frame(normal);
-  v3 wo = to_local(fr, -incoming);
-  v3 wi = to_local(fr, to_light);
   float light_cos = fmaxf(dot(normal, -to_light), 0.0f);
   float weight = light.area * light_cos * frcp(distance * distance);
-  v3 f = bsdf_eval(fl, m, albedo, wo, wi);
+  // Only the microfacet model looks at the directions; every other BxDF::eval is a constant
+  // (src/material.cpp:153,164,242), so the light's frame is built for that model alone.
+  v3 f;
+  if (m.type == 16u) {
+    Frame fr = make_frame(normal);
+    f = bsdf_eval(fl, m, albedo, to_local(fr, -incoming), to_local(fr, to_light));
+  } else {
+    f = bsdf_eval(fl, m, albedo, V3(0.0f, 1.0f, 0.0f), V3(0.0f, 1.0f, 0.0f));
+  }
   ps.pending = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
   ps.light_id = light.id;
   to_light_out = to_light;

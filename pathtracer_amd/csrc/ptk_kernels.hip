@@ -211,8 +211,8 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   // Every lane keeps one query in flight.  The wave alternates uniform phases, each run only when
   // enough lanes want it (or when no lane is traversing any more, so that everything drains):
   //   descend  - lanes at an inner node visit it, repeated while at least kDescendMin lanes are at one
-  //              (or while no lane is at a leaf);
-  //   leaves   - lanes at a leaf intersect its primitives;
+  //              (or while no lane holds a leaf);
+  //   leaves   - lanes intersect the primitives of the leaves they hold or stand at;
   //   lit      - lanes whose shadow ray has finished add the light and start the path's next segment;
   //   shade    - lanes whose path segment has finished shade the hit and start a shadow ray or the
   //              next segment;
@@ -220,16 +220,26 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   // Lanes not in the running phase keep their state (node in a register, stack in LDS).
   PTK_PHASE(uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
   bool need = false;  // this lane's path has ended and it has not been given a new work item yet
+  int32_t held = kTravDone;  // a leaf the lane has reached but not intersected yet (kTravDone: none)
   for (;;) {
+    // A lane that reaches a leaf puts it aside and goes on descending with the others; it stops only at a
+    // second leaf.  The leaf phase then intersects the leaf put aside and the one the lane stands at.
+    // (Descending past a leaf uses a closest-hit distance that is not up to date, which costs a few extra
+    // node visits and never a wrong answer.  Holding one leaf: +13 % frame rate; holding two: -6 %.)
     for (;;) {
-      bool want = trav_at_inner(ps.tr);
-      int n_want = __popcll(__ballot(want));
-      // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no lane is at a leaf
-      if (n_want == 0 || (n_want < kDescendMin && __ballot(trav_at_leaf(ps.tr)) != 0ull)) break;
+      if (trav_at_leaf(ps.tr) && held == kTravDone) { held = ps.tr.node; ps.tr.node = (int32_t)st.pop(); }
+      const bool want = trav_at_inner(ps.tr);
+      const int n_want = __popcll(__ballot(want));
+      // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no leaf is held
+      if (n_want == 0 || (n_want < kDescendMin && __ballot(held != kTravDone) != 0ull)) break;
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
-    PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(trav_at_leaf(ps.tr))); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
+    PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
+    if (held != kTravDone) {
+      if (trav_leaf_prims<STATS>(ps.tr, held, sc, cnt)) ps.tr.node = kTravDone;
+      held = kTravDone;
+    }
     if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
     const bool done = trav_done(ps.tr);
     const bool waiting = ps.alive && done && !need;

@@ -197,11 +197,12 @@ PTK_HD PrimRec load_prim(const SceneView& sc, uint32_t byte_offset)  // 32-bit b
   return *reinterpret_cast<const PrimRec*>(reinterpret_cast<const char*>(sc.prims) + byte_offset);
 }
 
-// Intersect the primitives of one leaf.
-template <class Stack, bool STATS>
-PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+// Intersect the primitives of the leaf with code `node` (a negative child link).  Returns true when
+// the query is decided and needs no further traversal (see Traversal::t_stop).
+template <bool STATS>
+PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Counters& cnt)
 {
-  const uint32_t leaf = ~(uint32_t)tr.node;
+  const uint32_t leaf = ~(uint32_t)node;
   const uint32_t count = (leaf & 7u) + 1u;
   uint32_t off = (leaf >> 3) * (uint32_t)sizeof(PrimRec);
   // the next record is fetched while this one is tested
@@ -213,8 +214,15 @@ PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& c
     trav_test_prim<STATS>(tr, p, cnt);
     p = next;
   }
+  return (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);
+}
+
+// Intersect the leaf the lane is at, then go on with the node on top of the stack.
+template <class Stack, bool STATS>
+PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+{
+  const bool decided = trav_leaf_prims<STATS>(tr, tr.node, sc, cnt);
   const int32_t next_node = (int32_t)st.pop();
-  const bool decided = (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);  // see Traversal::t_stop
   tr.node = decided ? kTravDone : next_node;
 }
 

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
   tr.node = kTravDone;
   tr.o = tr.d = V3(0.f, 0.f, 0.f);
   long long mine = -1;  // the ray this lane is working on
+  int32_t held = kTravDone;
   bool alive = true;
   for (;;) {
     const bool done = trav_done(tr);
@@ -357,11 +358,16 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
         }
       }
     }
-    for (;;) {
+    for (;;) {  // as in render_kernel: a leaf is held while the lane keeps descending
+      if (trav_at_leaf(tr) && held == kTravDone) { held = tr.node; tr.node = (int32_t)st.pop(); }
       const bool want = trav_at_inner(tr);
       const int n_want = __popcll(__ballot(want));
-      if (n_want == 0 || (n_want < kDescendMin && __ballot(trav_at_leaf(tr)) != 0ull)) break;
+      if (n_want == 0 || (n_want < kDescendMin && __ballot(held != kTravDone) != 0ull)) break;
       if (want) trav_inner<LdsStack, STATS>(tr, st, sc, cnt);
+    }
+    if (held != kTravDone) {
+      if (trav_leaf_prims<STATS>(tr, held, sc, cnt)) tr.node = kTravDone;
+      held = kTravDone;
     }
     if (trav_at_leaf(tr)) trav_leaf<LdsStack, STATS>(tr, st, sc, cnt);
   }

@@ -28,9 +28,9 @@ constexpr int kBlock = 64;  // one wave per workgroup: a finished wave frees its
 constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 
 // Wave scheduling knobs of the render kernel (see its main loop).  Measured on the 81,920-triangle
-// mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: -7%,
-// 24: -2%; lit 16: -9%, 4: -1%; shade 32: -9%, 16: -4%; item 16: -9%, 1: -6%; 3 waves
-// per SIMD: same, 5 (96 VGPRs, spills): -4%.
+// mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: -8%,
+// 12: -2%, 20: -1%, 24: -3%; lit 4: same, 16: -1%; shade 16: -1%, 32: -1%; item 4: -1%, 16: -3%;
+// 3 waves per SIMD: same, 5 (96 VGPRs, spills): -4%.
 #ifndef PTK_DESCEND_MIN
 #define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
 #endif

@@ -177,7 +177,10 @@ int ptk_set_flags(ptk_ctx* ctx, const ptk_flags* flags);
 int ptk_bind_accum(ptk_ctx* ctx, float* device_rgbw);
 int ptk_reset_accum(ptk_ctx* ctx);
 
-/* -- Renderer::render (src/renderer.cpp:27-52): launches the path kernel; asynchronous. */
+/* -- Renderer::render (src/renderer.cpp:27-52): launches the path kernel; asynchronous.
+ * The same sequence of calls gives the same bits every time; how a frame is split into calls
+ * (rows, bands, sample batches) only changes the fp32 order in which a pixel's samples are summed.
+ * May allocate device memory the first time an image size is rendered. */
 int ptk_render(ptk_ctx* ctx, const ptk_render_params* params);
 /* -- the buffer Renderer::save_image reads (src/renderer.cpp:186): per-pixel mean radiance,
  * row 0 = top, W*H*3 floats, host memory.  Blocks until rendering has finished.

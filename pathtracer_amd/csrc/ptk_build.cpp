@@ -254,6 +254,7 @@ SceneView HostScene::host_view() const
   v.textures = textures.data();
   v.texels = texels.data();
   v.n_prims = n_prims;
+  v.n_triangles = n_triangles;
   v.n_lights = (int32_t)lights.size();
   v.n_nodes = (int32_t)nodes.size();
   v.n_materials = (int32_t)materials.size();
@@ -268,7 +269,9 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
   out = HostScene();
   if (d.n_triangles < 0 || d.n_spheres < 0 || d.n_materials < 0 || d.n_textures < 0) return "negative count";
   const int64_t n_total = (int64_t)d.n_triangles + (int64_t)d.n_spheres;
-  if (n_total >= (1 << 28)) return "too many primitives (limit 2^28 - 1)";
+  // a tree of depth kMaxTreeDepth with kMaxLeafSize primitives per leaf holds this many at most
+  if (n_total > ((int64_t)kMaxLeafSize << kMaxTreeDepth) || n_total >= (1 << 28))
+    return "too many primitives (limit " + std::to_string(std::min<int64_t>((int64_t)kMaxLeafSize << kMaxTreeDepth, (1 << 28) - 1)) + ")";
   if (d.n_triangles > 0 && (!d.tri_pos || !d.tri_nrm || !d.tri_uv || !d.tri_material)) return "null triangle array";
   if (d.n_spheres > 0 && (!d.sphere_center || !d.sphere_radius || !d.sphere_material)) return "null sphere array";
   if (d.n_materials > 0 && !d.materials) return "null material array";
@@ -277,6 +280,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
   if (d.background_texture >= d.n_textures) return "background_texture out of range";
   const int n = (int)n_total;
   out.n_prims = n;
+  out.n_triangles = d.n_triangles;
 
   // --- textures ------------------------------------------------------------
   for (int i = 0; i < d.n_textures; i++) {

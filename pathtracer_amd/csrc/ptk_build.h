@@ -29,6 +29,7 @@ struct HostScene {
   int32_t background_is_color = 0;
   float background_color[3] = {-1.f, -1.f, -1.f};
   int32_t n_prims = 0;
+  int32_t n_triangles = 0;
   int32_t max_depth = 0;
   int32_t max_leaf = 0;
 

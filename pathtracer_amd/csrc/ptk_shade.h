@@ -287,7 +287,6 @@ struct PathState {
   v3 beta, L;
   v3 pending;          // shadow ray in flight: radiance to add if it reaches the light
   v3 next_d;           // shadow ray in flight: direction of the path segment that follows it
-  uint32_t light_id;   // shadow ray in flight: the light it must reach
   uint32_t origin_id;  // primitive the current path vertex lies on
   uint32_t slot;       // pixel slot of the tile that the path belongs to
   int32_t depth;
@@ -312,7 +311,7 @@ struct SumAccum {  // accumulator of a one-pixel tile
 PTK_HD void path_init(PathState& ps)
 {
   ps.L = ps.beta = ps.pending = ps.next_d = V3(0.0f, 0.0f, 0.0f);
-  ps.light_id = ps.origin_id = kNoPrim;
+  ps.origin_id = kNoPrim;
   ps.slot = 0;
   ps.depth = 0;
   ps.shadow = ps.prev_specular = false;
@@ -375,7 +374,8 @@ PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, con
 // the visibility query is evaluated here; the result waits in ps.pending until the shadow ray returns.
 // Returns false when no shadow ray is needed.
 PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s,
-                      v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out, float& t_stop_out)
+                      v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out, float& t_stop_out,
+                      uint32_t& light_id_out)
 {
   if (sc.n_lights == 0) return false;
   int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
@@ -425,7 +425,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
     f = bsdf_eval(fl, m, albedo, V3(0.0f, 1.0f, 0.0f), V3(0.0f, 1.0f, 0.0f));
   }
   ps.pending = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
-  ps.light_id = light.id;
+  light_id_out = light.id;
   to_light_out = to_light;
   distance_out = distance;
   // A flat light is met by this ray at `distance` and nowhere else, so any other primitive hit clearly
@@ -476,13 +476,15 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   ps.tr.o = s.point;
   v3 to_light;
   float distance, t_stop;
+  uint32_t light_id;
   if (fl.direct_light_sampling && !specular &&
-      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop)) {
+      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id)) {
     ps.shadow = true;
     ps.next_d = next_d;
     cnt.queries++;
     // the light is at `distance`: nothing farther can be the closest hit that counts
-    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, ps.light_id, t_stop);
+    // the light the ray must reach stays in the query (Traversal::target) until the result is used
+    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, light_id, t_stop);
     return false;
   }
   return path_next_segment(ps, st, sc, pp, fl, next_d, cnt);
@@ -494,7 +496,7 @@ template <class Stack>
 PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
                                 Counters& cnt)
 {
-  if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
+  if (ps.tr.hit.id == ps.tr.target) ps.L += ps.pending;  // src/renderer.cpp:146
   return path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
 }
 
@@ -506,7 +508,7 @@ PTK_HD bool path_consume(PathState& ps, Stack& st, const SceneView& sc, const Fl
 {
   bool ended;
   if (ps.shadow) {
-    if (ps.tr.hit.id == ps.light_id) ps.L += ps.pending;  // src/renderer.cpp:146
+    if (ps.tr.hit.id == ps.tr.target) ps.L += ps.pending;  // src/renderer.cpp:146
     ended = path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
   } else {
     ended = path_shade(ps, st, sc, fl, pp, cnt);

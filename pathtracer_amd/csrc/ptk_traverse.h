@@ -28,8 +28,7 @@ constexpr float kTMax = 1e9f;
 
 struct Hit {
   float t;
-  uint32_t id;    // reference primitive id, kNoPrim = miss
-  uint32_t kind;  // PrimKind
+  uint32_t id;    // reference primitive id, kNoPrim = miss (ids below SceneView::n_triangles are triangles)
   float u, v;     // triangle: weights of v1 and v2
 };
 
@@ -146,7 +145,6 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   tr.oi = o * tr.inv;
   tr.hit.t = tmax;
   tr.hit.id = kNoPrim;
-  tr.hit.kind = kTriangle;
   tr.hit.u = tr.hit.v = 0.0f;
   tr.skip_id = skip_id;
   st.reset();
@@ -189,7 +187,7 @@ PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
     ok = hit_sphere(p, tr.o, tr.d, tr.hit.t, id == tr.skip_id, t);
     u = v = 0.0f;
   }
-  if (ok) { tr.hit.t = t; tr.hit.id = id; tr.hit.kind = kind; tr.hit.u = u; tr.hit.v = v; }
+  if (ok) { tr.hit.t = t; tr.hit.id = id; tr.hit.u = u; tr.hit.v = v; }
 }
 
 PTK_HD PrimRec load_prim(const SceneView& sc, uint32_t byte_offset)  // 32-bit byte offset, as for the nodes
@@ -262,7 +260,7 @@ PTK_HD void make_surface(const SceneView& sc, v3 o, v3 d, const Hit& hit, Surfac
   s.uv[0] = s.uv[1] = 0.0f;
   v3 normal;
   bool keep_normal = false;
-  if (hit.kind == kTriangle) {
+  if (hit.id < (uint32_t)sc.n_triangles) {
     float w0 = 1.0f - hit.u - hit.v;
     normal = V3(sh.n0[0], sh.n0[1], sh.n0[2]) * w0 + V3(sh.n1[0], sh.n1[1], sh.n1[2]) * hit.u +
              V3(sh.n2[0], sh.n2[1], sh.n2[2]) * hit.v;

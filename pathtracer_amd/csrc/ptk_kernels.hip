@@ -248,11 +248,11 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     const bool idle = __ballot(!done) == 0ull;  // no lane is traversing: everything that waits must run now
     if (idle && n_lit + n_shade + __popcll(__ballot(need)) == 0) break;
     if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
-      if (lit && path_consume_shadow(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot, ps.L); need = true; }
+      if (lit && path_consume_shadow(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
     }
     if (n_shade >= PTK_SHADE_MIN || (idle && n_shade > 0)) {
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
-      if (shade && path_shade(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot, ps.L); need = true; }
+      if (shade && path_shade(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
     }
     const int n_need = __popcll(__ballot(need));
     if (n_need >= PTK_ITEM_MIN || (idle && n_need > 0)) {
@@ -682,7 +682,8 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
     return fail(ctx, PTK_ERR_LIMIT, "ptk_render: sample index exceeds 2^31 - 1");
   if (p->samples > (1 << 25)) return fail(ctx, PTK_ERR_LIMIT, "ptk_render: at most 2^25 samples per call");
   RenderArgs ra;
-  ra.samples = p->samples; ra.max_bounce = p->max_bounce; ra.seed = p->seed;
+  ra.samples = p->samples; ra.seed = p->seed;
+  ra.max_bounce = p->max_bounce < (1 << 23) ? p->max_bounce : (1 << 23);  // the range of the path state's depth field
   ra.sample_first = p->sample_first; ra.sample_stride = p->sample_stride;
   ra.row_begin = p->row_begin;
   ra.row_end = p->row_end <= 0 ? ctx->cam.height : p->row_end;

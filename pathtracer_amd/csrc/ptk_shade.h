@@ -287,12 +287,12 @@ struct PathState {
   v3 beta, L;
   v3 pending;          // shadow ray in flight: radiance to add if it reaches the light
   v3 next_d;           // shadow ray in flight: direction of the path segment that follows it
-  uint32_t origin_id;  // primitive the current path vertex lies on
-  uint32_t slot;       // pixel slot of the tile that the path belongs to
-  int32_t depth;
+  uint32_t bits;       // pixel slot of the tile that the path belongs to (bits 0-7) and depth (bits 8 up), one register
   bool shadow;         // the query in flight is a shadow ray
   bool prev_specular;
   bool alive;          // false once the tile has no work items left for this lane
+  PTK_HD uint32_t slot() const { return bits & 0xffu; }
+  PTK_HD int32_t depth() const { return (int32_t)(bits >> 8); }
 };
 
 struct PathParams {
@@ -311,9 +311,7 @@ struct SumAccum {  // accumulator of a one-pixel tile
 PTK_HD void path_init(PathState& ps)
 {
   ps.L = ps.beta = ps.pending = ps.next_d = V3(0.0f, 0.0f, 0.0f);
-  ps.origin_id = kNoPrim;
-  ps.slot = 0;
-  ps.depth = 0;
+  ps.bits = 0;
   ps.shadow = ps.prev_specular = false;
   ps.alive = true;
   ps.tr.node = kTravDone;
@@ -340,31 +338,29 @@ PTK_HD bool path_begin_item(PathState& ps, Stack& st, const SceneView& sc, const
   camera_ray(cam, px, py, ps.g, o, d);
   cnt.camera_rays++;
   if (pp.max_bounce <= 0) return true;  // every sample is black without a single query (src/renderer.cpp:59-61)
-  ps.slot = slot;
-  ps.L = V3(0.0f, 0.0f, 0.0f);
-  ps.beta = V3(1.0f, 1.0f, 1.0f);
+  ps.bits = slot;  // depth 0
   ps.prev_specular = false;
   ps.shadow = false;
-  ps.depth = 0;
-  ps.origin_id = kNoPrim;
+  ps.L = V3(0.0f, 0.0f, 0.0f);
+  ps.beta = V3(1.0f, 1.0f, 1.0f);
   cnt.segments++;
   cnt.queries++;
   trav_begin(ps.tr, st, sc, o, d, kTMax, kNoPrim);
   return false;
 }
 
-// Start the path segment that leaves the current vertex in direction d.  Returns true when the
-// bounce limit ends the path instead.
+// Start the path segment that leaves the current vertex (on primitive from_id) in direction d.
+// Returns true when the bounce limit ends the path instead.
 template <class Stack>
 PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, const PathParams& pp, const FlagView& fl,
-                              v3 d, Counters& cnt)
+                              v3 d, uint32_t from_id, Counters& cnt)
 {
-  ps.depth++;
-  if (!fl.indirect_light_sampling || ps.depth >= pp.max_bounce) return true;
+  ps.bits += 1u << 8;  // one level deeper (max_bounce < 2^23 keeps the field from overflowing)
   ps.shadow = false;
+  if (!fl.indirect_light_sampling || ps.depth() >= pp.max_bounce) return true;
   cnt.segments++;
   cnt.queries++;
-  trav_begin(ps.tr, st, sc, ps.tr.o, d, kTMax, ps.origin_id);
+  trav_begin(ps.tr, st, sc, ps.tr.o, d, kTMax, from_id);
   return false;
 }
 
@@ -455,7 +451,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   v3 albedo = surface_albedo(sc, m, s);
   v3 emission = ld3(m.emission);
   float rr_weight = 1.0f;
-  if (fl.russian_roulette && ps.depth > 3) {  // src/renderer.cpp:78-90
+  if (fl.russian_roulette && ps.depth() > 3) {  // src/renderer.cpp:78-90
     float p = luma(albedo);
     if (rnd(ps.g) >= p) {
       ps.L += ps.beta * emission;
@@ -468,11 +464,10 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   v3 wi = bsdf_sample(fl, m, s.inside, wo, ps.g);
   bool specular = (m.flags & kMatSpecular) != 0;
   v3 scale = ps.beta * rr_weight;
-  if (!fl.direct_light_sampling || ps.depth == 0 || specular || ps.prev_specular) ps.L += scale * emission;
+  if (!fl.direct_light_sampling || ps.depth() == 0 || specular || ps.prev_specular) ps.L += scale * emission;
   v3 next_d = to_world(fr, wi);  // not renormalised, as in the reference (src/renderer.cpp:121)
   ps.beta = scale * bsdf_eval(fl, m, albedo, wo, wi);
   ps.prev_specular = specular;
-  ps.origin_id = s.id;
   ps.tr.o = s.point;
   v3 to_light;
   float distance, t_stop;
@@ -487,7 +482,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, light_id, t_stop);
     return false;
   }
-  return path_next_segment(ps, st, sc, pp, fl, next_d, cnt);
+  return path_next_segment(ps, st, sc, pp, fl, next_d, s.id, cnt);
 }
 
 // A shadow ray's query has finished: add the light's contribution if the light is what it reached,
@@ -497,7 +492,8 @@ PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, c
                                 Counters& cnt)
 {
   if (ps.tr.hit.id == ps.tr.target) ps.L += ps.pending;  // src/renderer.cpp:146
-  return path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
+  // the shadow ray left the vertex the next segment leaves: same origin, same primitive to skip
+  return path_next_segment(ps, st, sc, pp, fl, ps.next_d, ps.tr.skip_id, cnt);
 }
 
 // The lane's query has finished: use its result and set up the next query of the path.  Returns
@@ -509,11 +505,11 @@ PTK_HD bool path_consume(PathState& ps, Stack& st, const SceneView& sc, const Fl
   bool ended;
   if (ps.shadow) {
     if (ps.tr.hit.id == ps.tr.target) ps.L += ps.pending;  // src/renderer.cpp:146
-    ended = path_next_segment(ps, st, sc, pp, fl, ps.next_d, cnt);
+    ended = path_next_segment(ps, st, sc, pp, fl, ps.next_d, ps.tr.skip_id, cnt);
   } else {
     ended = path_shade(ps, st, sc, fl, pp, cnt);
   }
-  if (ended) acc.add(ps.slot, ps.L);
+  if (ended) acc.add(ps.slot(), ps.L);
   return ended;
 }
 

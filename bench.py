@@ -103,7 +103,7 @@ def main():
 
     sd = build_scene(ARGS.workload, ARGS.width, ARGS.height)
     ctx = native.Context(local_rank)
-    ctx.upload_scene(sd)
+    ctx.upload_scene(sd, ARGS.builder)
     ctx.set_camera(sd.camera)
     info = ctx.scene_info()
     accum = torch.zeros((ARGS.height, ARGS.width, 4), dtype=torch.float32, device=dev)
@@ -182,7 +182,8 @@ def main():
             "higher_is_better": True, "scaling": "weak" if ARGS.split == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{ARGS.workload}: {WORKLOADS[ARGS.workload]}; {ARGS.width}x{ARGS.height}, "
                                    f"{ARGS.spp} spp per GPU, {ARGS.bounces} bounces",
-                       "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"],
+                       "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"], "bvh_builder": "device" if info["builder"] else "host",
+                       "scene_upload_ms": round(info["upload_ms"], 2), "device_build_ms": round(info["device_build_ms"], 3),
                        "split": (f"{ARGS.split} split, one RCCL reduce per frame" if world > 1 else "none"),
                        "launches_per_frame": st["launches"] // max(1, ARGS.steps)},
             "ms_per_frame": elapsed / ARGS.steps * 1e3,
@@ -224,6 +225,8 @@ if __name__ == "__main__":
     ap.add_argument("--stats-spp", type=int, default=4, help="samples per pixel of the instrumented (test-counting) pass")
     ap.add_argument("--split", default="spp", choices=["spp", "tile"],
                     help="how N > 1 GPUs share a frame: interleaved sample indices or interleaved row bands")
+    ap.add_argument("--builder", default=None, choices=["host", "device"],
+                    help="tree builder (default: host surface-area-heuristic build; device: linear BVH built on the GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ARGS = ap.parse_args()
     _w, _h, _s, _b = WORKLOAD_DEFAULTS.get(ARGS.workload, (1024, 1024, 1024, 3))

@@ -153,6 +153,10 @@ typedef struct {
 typedef struct {
   int32_t n_primitives, n_lights, n_nodes, max_depth, max_leaf_size, traversal_kind;
   uint64_t node_bytes, prim_bytes, shading_bytes, texture_bytes;
+  int32_t builder;         /* PTK_BUILDER_* that built the tree in use */
+  int32_t reserved;
+  double upload_ms;        /* host wall time of the ptk_upload_scene call (flattening, tree, copies) */
+  double device_build_ms;  /* device time of the tree build; 0 for a host-built tree */
 } ptk_scene_info;
 
 /* -- lifetime ---------------------------------------------------------------- */
@@ -165,6 +169,18 @@ const char* ptk_last_error(const ptk_ctx* ctx);
  * is the point after which the scene is immutable.  Builds the acceleration structure on
  * the host and uploads everything. */
 int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
+/* Same with the tree builder named (BVH::construct, src/bvh.cpp:54-83, is the reference's only one):
+ *   PTK_BUILDER_HOST_SAH     binned surface-area-heuristic build on the host's cores: the tree the
+ *                            render rates are quoted on; about a second per million triangles.
+ *   PTK_BUILDER_DEVICE_LBVH  linear BVH built on the GPU in milliseconds, for scenes that are loaded or
+ *                            changed often; rays visit more nodes in it.  Scenes of fewer than 64
+ *                            primitives are built on the host either way.
+ * Which tree is used never changes the closest hit of a ray (apart from exact ties in distance).
+ * ptk_upload_scene takes the builder from the environment variable PTK_BUILDER (host | device),
+ * host when unset. */
+#define PTK_BUILDER_HOST_SAH 0
+#define PTK_BUILDER_DEVICE_LBVH 1
+int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder);
 int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out);
 
 /* -- camera / renderer state: Renderer::Renderer (src/renderer.cpp:19-25) allocates the

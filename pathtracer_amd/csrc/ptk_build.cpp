@@ -264,7 +264,7 @@ SceneView HostScene::host_view() const
   return v;
 }
 
-std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
+std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_tree)
 {
   out = HostScene();
   if (d.n_triangles < 0 || d.n_spheres < 0 || d.n_materials < 0 || d.n_textures < 0) return "negative count";
@@ -418,6 +418,28 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out)
     e.child0 = e.child1 = leaf_code(0, 1);
     out.nodes.push_back(e);
     out.prims.assign(1, by_id[0]);
+    return std::string();
+  }
+  if (!with_tree && n >= kDeviceBuildMin) {
+    out.prims = std::move(by_id);
+    out.prim_boxes.resize(6 * (size_t)n);
+    Box cb;
+    cb.reset();
+    float diag2 = 0.f;
+    for (int i = 0; i < n; i++) {
+      const Box& b = boxes[i];
+      float c[3], e2 = 0.f;
+      for (int a = 0; a < 3; a++) {
+        out.prim_boxes[6 * (size_t)i + a] = b.lo[a];
+        out.prim_boxes[6 * (size_t)i + 3 + a] = b.hi[a];
+        c[a] = 0.5f * (b.lo[a] + b.hi[a]);
+        e2 += (b.hi[a] - b.lo[a]) * (b.hi[a] - b.lo[a]);
+      }
+      cb.grow(c);
+      diag2 = std::max(diag2, e2);
+    }
+    for (int a = 0; a < 3; a++) { out.centroid_lo[a] = cb.lo[a]; out.centroid_hi[a] = cb.hi[a]; }
+    out.max_diagonal = std::sqrt(diag2);
     return std::string();
   }
   const bool timing = getenv("PTK_BUILD_TIMING") != nullptr;

@@ -32,13 +32,21 @@ struct HostScene {
   int32_t n_triangles = 0;
   int32_t max_depth = 0;
   int32_t max_leaf = 0;
+  // Filled instead of `nodes` when the tree is left to the device builder: `prims` is then in id order and
+  // these are the padded boxes (lo.xyz, hi.xyz per primitive) the tree has to be built over.
+  std::vector<float> prim_boxes;
+  float centroid_lo[3] = {0.f, 0.f, 0.f}, centroid_hi[3] = {0.f, 0.f, 0.f};  // bounds of the box centres
+  float max_diagonal = 0.f;                                                  // longest box diagonal
 
   // Pointers into this object's own vectors (host memory).
   SceneView host_view() const;
 };
 
 // Returns an empty string on success, otherwise the reason the description was rejected.
-std::string build_host_scene(const ptk_scene_desc& desc, HostScene& out);
+// with_tree = false: everything except the tree (see HostScene::prim_boxes); scenes of fewer than
+// kDeviceBuildMin primitives get their tree here regardless.
+constexpr int kDeviceBuildMin = 64;
+std::string build_host_scene(const ptk_scene_desc& desc, HostScene& out, bool with_tree = true);
 
 CameraView make_camera_view(const ptk_camera& cam);
 FlagView make_flag_view(const ptk_flags* flags);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +21,7 @@
 
 #include "../../include/ptk.h"
 #include "ptk_build.h"
+#include "ptk_lbvh.h"
 #include "ptk_shade.h"
 
 namespace ptk {
@@ -420,6 +422,10 @@ struct ptk_ctx {
   void* d_nodes = nullptr; void* d_prims = nullptr; void* d_shade = nullptr; void* d_materials = nullptr;
   void* d_lights = nullptr; void* d_textures = nullptr; void* d_texels = nullptr;
   uint64_t texel_bytes = 0;
+  int32_t n_nodes = 0;
+  int32_t builder = 0;    // what built the tree in use (PTK_BUILDER_*)
+  double upload_ms = 0.0; // host wall time of the whole ptk_upload_scene call
+  double tree_ms = 0.0;   // device time of the tree build, 0 for a host-built tree
   // camera / accumulation
   bool have_camera = false;
   CameraView cam;
@@ -568,22 +574,53 @@ int ptk_destroy(ptk_ctx* ctx)
 
 const char* ptk_last_error(const ptk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
+int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder)
 {
   if (!ctx) return PTK_ERR_INVALID;
   if (!scene) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: scene is NULL");
+  if (builder != PTK_BUILDER_HOST_SAH && builder != PTK_BUILDER_DEVICE_LBVH)
+    return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: unknown builder");
   PTK_HIP(hipSetDevice(ctx->device));
   PTK_HIP(hipStreamSynchronize(ctx->stream));
   free_scene(ctx);
-  std::string why = build_host_scene(*scene, ctx->host);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::string why = build_host_scene(*scene, ctx->host, builder == PTK_BUILDER_HOST_SAH);
   if (!why.empty()) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: " + why);
-  // the kernels' per-lane stacks hold kStackDepth entries: a sentinel, one per level, one of scratch
-  if (ctx->host.max_depth > kMaxTreeDepth || kMaxTreeDepth + 2 > kStackDepth)
-    return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
   HostScene& h = ctx->host;
+  const bool on_device = !h.prim_boxes.empty();  // small scenes get their tree on the host whatever was asked
+  ctx->builder = on_device ? PTK_BUILDER_DEVICE_LBVH : PTK_BUILDER_HOST_SAH;
   int rc;
-  if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
-  if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
+  if (on_device) {
+    void *d_boxes = nullptr, *d_by_id = nullptr;
+    if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) return rc;
+    if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); return rc; }
+    DeviceTree tree;
+    why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
+                            h.centroid_hi, h.max_diagonal, tree);
+    (void)hipFree(d_boxes);
+    (void)hipFree(d_by_id);
+    if (!why.empty()) return fail(ctx, PTK_ERR_HIP, "ptk_upload_scene: " + why);
+    ctx->d_nodes = tree.nodes;
+    ctx->d_prims = tree.prims;
+    h.max_depth = tree.max_depth;
+    h.max_leaf = tree.max_leaf;
+    ctx->n_nodes = tree.n_nodes;
+    ctx->tree_ms = tree.build_ms;
+    std::vector<float>().swap(h.prim_boxes);
+    std::vector<PrimRec>().swap(h.prims);  // id order: not the device's order, so not kept
+  } else {
+    ctx->n_nodes = (int32_t)h.nodes.size();
+    ctx->tree_ms = 0.0;
+  }
+  // the kernels' per-lane stacks hold kStackDepth entries: a sentinel, one per level, one of scratch
+  if (h.max_depth > kMaxTreeDepth || kMaxTreeDepth + 2 > kStackDepth) {
+    free_scene(ctx);
+    return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
+  }
+  if (!on_device) {
+    if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
+    if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
+  }
   if ((rc = upload(ctx, &ctx->d_shade, h.shade))) return rc;
   if ((rc = upload(ctx, &ctx->d_materials, h.materials))) return rc;
   if ((rc = upload(ctx, &ctx->d_lights, h.lights))) return rc;
@@ -591,6 +628,7 @@ int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
   if ((rc = upload(ctx, &ctx->d_texels, h.texels))) return rc;
   PTK_HIP(hipStreamSynchronize(ctx->stream));
   SceneView v = h.host_view();
+  v.n_nodes = ctx->n_nodes;
   v.nodes = (const NodePair*)ctx->d_nodes;
   v.prims = (const PrimRec*)ctx->d_prims;
   v.shade = (const ShadeRec*)ctx->d_shade;
@@ -601,8 +639,19 @@ int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
   ctx->view = v;
   ctx->texel_bytes = h.texels.size();
   std::vector<uint8_t>().swap(h.texels);  // the largest host copy is no longer needed
+  ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
   return PTK_OK;
+}
+
+int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
+{
+  int32_t builder = PTK_BUILDER_HOST_SAH;
+  if (const char* e = getenv("PTK_BUILDER")) {
+    if (std::strcmp(e, "device") == 0) builder = PTK_BUILDER_DEVICE_LBVH;
+    else if (std::strcmp(e, "host") != 0 && ctx) return fail(ctx, PTK_ERR_INVALID, "PTK_BUILDER must be host or device");
+  }
+  return ptk_upload_scene_ex(ctx, scene, builder);
 }
 
 int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
@@ -611,14 +660,18 @@ int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
   const HostScene& h = ctx->host;
   out->n_primitives = h.n_prims;
   out->n_lights = (int32_t)h.lights.size();
-  out->n_nodes = (int32_t)h.nodes.size();
+  out->n_nodes = ctx->n_nodes;
   out->max_depth = h.max_depth;
   out->max_leaf_size = h.max_leaf;
   out->traversal_kind = 0;
-  out->node_bytes = h.nodes.size() * sizeof(NodePair);
-  out->prim_bytes = h.prims.size() * sizeof(PrimRec);
+  out->node_bytes = (uint64_t)ctx->n_nodes * sizeof(NodePair);
+  out->prim_bytes = (uint64_t)std::max(h.n_prims, 1) * sizeof(PrimRec);
   out->shading_bytes = h.shade.size() * sizeof(ShadeRec) + h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec);
   out->texture_bytes = ctx->texel_bytes;
+  out->builder = ctx->builder;
+  out->reserved = 0;
+  out->upload_ms = ctx->upload_ms;
+  out->device_build_ms = ctx->tree_ms;
   return PTK_OK;
 }
 

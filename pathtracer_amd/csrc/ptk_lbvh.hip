@@ -1,0 +1,353 @@
+// On-device tree construction (see ptk_lbvh.h).
+//
+//   1. key_kernel      one 64-bit sort key per primitive: 16 bits each of the box centre's x, y, z inside
+//                      the scene's centre bounds and of the box diagonal relative to the longest one,
+//                      interleaved size-first.  Carrying the size in the key keeps the few large
+//                      primitives of a scene (walls, floors) together near the top of the tree instead
+//                      of scattering them over leaves of small ones, whose boxes they would blow up.
+//   2. rocprim radix sort of (key, primitive) pairs.
+//   3. split_level_kernel, one launch per tree level: every node of the level splits its range of
+//      the sorted sequence where the highest differing key bit flips (binary search), or at the
+//      median when the keys are equal or when the larger side could not be finished within the depth
+//      limit any more, down to single primitives (or small leaves where the depth limit is near).  The host reads one
+//      counter per level (the number of nodes so far) - at most kMaxTreeDepth small copies.
+//   4. fit_level_kernel, deepest level first: child boxes from the primitives' boxes (leaves) or from
+//      the child's own record (inner nodes); subtrees of at most kMaxLeafSize primitives are merged into one
+//      leaf where the surface-area heuristic prefers that.
+//   5. compact_kernel: the nodes still in use are packed (prefix sum over the in-use flags) and their links
+//      renumbered; gather_kernel: primitive records into leaf order.
+#include "ptk_lbvh.h"
+
+#include <cstring>  // rocprim headers use memset without including it
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace ptk {
+
+namespace {
+
+constexpr int kBuildBlock = 256;
+
+struct BuildRange {
+  uint32_t first, count;
+};
+
+struct KeyParams {
+  float lo[3], scale[3];
+  float size_scale;
+};
+
+// bit k of a 16-bit value -> bit 4k
+__device__ inline uint64_t spread4(uint32_t v)
+{
+  uint64_t x = v & 0xffffu;
+  x = (x | (x << 24)) & 0x000000ff000000ffull;
+  x = (x | (x << 12)) & 0x000f000f000f000full;
+  x = (x | (x << 6)) & 0x0303030303030303ull;
+  x = (x | (x << 3)) & 0x1111111111111111ull;
+  return x;
+}
+
+__device__ inline uint32_t quantise16(float v)
+{
+  float q = fminf(fmaxf(v, 0.0f), 65535.0f);
+  return (uint32_t)q;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void key_kernel(const float* __restrict__ boxes, int32_t n, KeyParams kp,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ order)
+{
+  int32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= n) return;
+  const float* b = boxes + 6 * (size_t)i;
+  float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+  uint32_t qx = quantise16((0.5f * (b[0] + b[3]) - kp.lo[0]) * kp.scale[0]);
+  uint32_t qy = quantise16((0.5f * (b[1] + b[4]) - kp.lo[1]) * kp.scale[1]);
+  uint32_t qz = quantise16((0.5f * (b[2] + b[5]) - kp.lo[2]) * kp.scale[2]);
+  uint32_t qs = quantise16(sqrtf(ex * ex + ey * ey + ez * ez) * kp.size_scale);
+  keys[i] = (spread4(qs) << 3) | (spread4(qx) << 2) | (spread4(qy) << 1) | spread4(qz);
+  order[i] = (uint32_t)i;
+}
+
+// Levels of median splitting needed until every part holds <= kMaxLeafSize primitives.
+__device__ inline int median_levels(uint32_t n)
+{
+  int l = 0;
+  while (n > (uint32_t)kMaxLeafSize) { n = (n + 1u) / 2u; l++; }
+  return l;
+}
+
+__device__ inline int32_t leaf_link(uint32_t first, uint32_t count) { return (int32_t) ~((first << 3) | (count - 1u)); }
+
+// Nodes [begin, end) are the inner nodes at `depth`; each holds a range of at least two primitives.
+__global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t* __restrict__ keys, BuildRange* ranges,
+                                                                  NodePair* nodes, uint32_t begin, uint32_t end, int depth,
+                                                                  uint32_t* counter)
+{
+  uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= end) return;
+  const BuildRange r = ranges[i];
+  const uint32_t a = r.first, b = r.first + r.count - 1u;
+  const uint64_t ka = keys[a], kb = keys[b];
+  uint32_t mid = 0;  // first primitive of the second part
+  bool by_key = ka != kb;
+  if (by_key) {
+    const int bit = 63 - __clzll((long long)(ka ^ kb));
+    uint32_t lo = a, hi = b;  // the bit is clear at lo and set at hi; everything above it is equal in the range
+    while (hi - lo > 1u) {
+      uint32_t m = lo + ((hi - lo) >> 1);
+      if ((keys[m] >> bit) & 1ull) hi = m; else lo = m;
+    }
+    mid = hi;
+    const uint32_t left = mid - a;
+    const uint32_t big = left > r.count - left ? left : r.count - left;
+    if (depth + 1 + median_levels(big) > kMaxTreeDepth) by_key = false;
+  }
+  if (!by_key) mid = a + (r.count + 1u) / 2u;
+  const uint32_t n0 = mid - a, n1 = r.count - n0;
+  // A part becomes a leaf when it is one primitive, or when it is small enough for a leaf and the depth limit
+  // leaves no room to split it down to single primitives.  Otherwise it is split further; the fitting pass
+  // merges small subtrees back into leaves where the surface-area heuristic prefers that.
+  auto child = [&](uint32_t first, uint32_t count) -> int32_t {
+    int to_one = 0;
+    while ((1u << to_one) < count) to_one++;
+    if (count == 1u || (count <= (uint32_t)kMaxLeafSize && depth + 1 + to_one > kMaxTreeDepth)) return leaf_link(first, count);
+    uint32_t idx = atomicAdd(counter, 1u);
+    ranges[idx] = BuildRange{first, count};
+    return (int32_t)idx;
+  };
+  const int32_t c0 = child(a, n0), c1 = child(mid, n1);
+  nodes[i].child0 = c0;
+  nodes[i].child1 = c1;
+  nodes[i].pad0 = nodes[i].pad1 = 0;
+}
+
+struct DevBox {
+  float lo[3], hi[3];
+};
+
+__device__ inline float half_area(const DevBox& b)
+{
+  float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+constexpr float kTraversalCost = 1.0f, kIntersectCost = 1.2f;  // the host builder's constants
+
+// Box of the child behind `link`.  An inner child whose own children are both leaves, of at most
+// kMaxLeafSize primitives together, is replaced by one leaf when testing all of them costs no more
+// (surface-area heuristic) than visiting the node first; `link` is updated then and the node is left unused.
+__device__ inline DevBox child_box(int32_t& link, const float* __restrict__ boxes, const uint32_t* __restrict__ order,
+                                   const NodePair* nodes)
+{
+  DevBox r;
+  if (link < 0) {
+    const uint32_t leaf = ~(uint32_t)link;
+    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+    for (int k = 0; k < 3; k++) { r.lo[k] = 3.0e38f; r.hi[k] = -3.0e38f; }
+    for (uint32_t j = 0; j < count; j++) {
+      const float* b = boxes + 6 * (size_t)order[first + j];
+      for (int k = 0; k < 3; k++) { r.lo[k] = fminf(r.lo[k], b[k]); r.hi[k] = fmaxf(r.hi[k], b[3 + k]); }
+    }
+  } else {
+    const NodePair c = nodes[link];
+    r.lo[0] = fminf(c.xy0.x, c.xy1.x); r.hi[0] = fmaxf(c.xy0.y, c.xy1.y);
+    r.lo[1] = fminf(c.xy0.z, c.xy1.z); r.hi[1] = fmaxf(c.xy0.w, c.xy1.w);
+    r.lo[2] = fminf(c.zz.x, c.zz.z);   r.hi[2] = fmaxf(c.zz.y, c.zz.w);
+    if (c.child0 < 0 && c.child1 < 0) {
+      const uint32_t l0 = ~(uint32_t)c.child0, l1 = ~(uint32_t)c.child1;
+      const uint32_t n0 = (l0 & 7u) + 1u, n1 = (l1 & 7u) + 1u;
+      if (n0 + n1 <= (uint32_t)kMaxLeafSize) {  // the two ranges are adjacent: l1 starts where l0 ends
+        const DevBox b0{{c.xy0.x, c.xy0.z, c.zz.x}, {c.xy0.y, c.xy0.w, c.zz.y}};
+        const DevBox b1{{c.xy1.x, c.xy1.z, c.zz.z}, {c.xy1.y, c.xy1.w, c.zz.w}};
+        const float a = half_area(r);
+        const float split = kTraversalCost * a + kIntersectCost * (half_area(b0) * (float)n0 + half_area(b1) * (float)n1);
+        const float leaf = kIntersectCost * a * (float)(n0 + n1);
+        if (leaf <= split) link = leaf_link(l0 >> 3, n0 + n1);
+      }
+    }
+  }
+  return r;
+}
+
+// Nodes [begin, end) are one level; every deeper level has been fitted already.
+__global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __restrict__ boxes,
+                                                                const uint32_t* __restrict__ order, NodePair* nodes,
+                                                                uint32_t begin, uint32_t end, uint32_t* __restrict__ live)
+{
+  uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= end) return;
+  int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
+  const DevBox b0 = child_box(c0, boxes, order, nodes), b1 = child_box(c1, boxes, order, nodes);
+  nodes[i].child0 = c0;
+  nodes[i].child1 = c1;
+  // A node merged into a leaf has only leaves below it, so whatever an inner link still points at is in use.
+  if (c0 >= 0) live[c0] = 1u;
+  if (c1 >= 0) live[c1] = 1u;
+  nodes[i].xy0 = f4{b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1]};
+  nodes[i].xy1 = f4{b1.lo[0], b1.hi[0], b1.lo[1], b1.hi[1]};
+  nodes[i].zz = f4{b0.lo[2], b0.hi[2], b1.lo[2], b1.hi[2]};
+}
+
+// Nodes in use move to their final, dense positions; inner links follow.
+__global__ __launch_bounds__(kBuildBlock) void compact_kernel(const NodePair* __restrict__ in, const uint32_t* __restrict__ live,
+                                                              const uint32_t* __restrict__ new_index, uint32_t n_nodes,
+                                                              NodePair* __restrict__ out)
+{
+  uint32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= n_nodes || !live[i]) return;
+  NodePair nd = in[i];
+  if (nd.child0 >= 0) nd.child0 = (int32_t)new_index[nd.child0];
+  if (nd.child1 >= 0) nd.child1 = (int32_t)new_index[nd.child1];
+  out[new_index[i]] = nd;
+}
+
+__global__ __launch_bounds__(kBuildBlock) void gather_kernel(const PrimRec* __restrict__ by_id,
+                                                             const uint32_t* __restrict__ order, int32_t n,
+                                                             PrimRec* __restrict__ out)
+{
+  int32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= n) return;
+  out[i] = by_id[order[i]];
+}
+
+struct Scratch {  // frees whatever was allocated when the build leaves, whichever way
+  std::vector<void*> ptrs;
+  ~Scratch() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  hipError_t alloc(void** p, size_t bytes)
+  {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+inline unsigned blocks_for(uint32_t n) { return (n + kBuildBlock - 1) / kBuildBlock; }
+
+}  // namespace
+
+#define LBVH_HIP(call)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) return std::string(#call) + ": " + hipGetErrorString(e_);      \
+  } while (0)
+
+std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n,
+                              const float centroid_lo[3], const float centroid_hi[3], float max_diagonal,
+                              DeviceTree& out)
+{
+  out = DeviceTree();
+  if (n < 2 * kMaxLeafSize) return "device tree build needs at least " + std::to_string(2 * kMaxLeafSize) + " primitives";
+  if ((int64_t)n > ((int64_t)kMaxLeafSize << kMaxTreeDepth)) return "too many primitives for the depth limit";
+  const uint32_t un = (uint32_t)n;
+  Scratch scratch;
+  uint64_t *keys_in = nullptr, *keys = nullptr;
+  uint32_t *order_in = nullptr, *order = nullptr, *counter = nullptr;
+  BuildRange* ranges = nullptr;
+  NodePair* nodes_full = nullptr;
+  void* sort_temp = nullptr;
+  LBVH_HIP(scratch.alloc((void**)&keys_in, un * sizeof(uint64_t)));
+  LBVH_HIP(scratch.alloc((void**)&keys, un * sizeof(uint64_t)));
+  LBVH_HIP(scratch.alloc((void**)&order_in, un * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&order, un * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&counter, sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&ranges, un * sizeof(BuildRange)));     // fewer than n inner nodes
+  LBVH_HIP(scratch.alloc((void**)&nodes_full, un * sizeof(NodePair)));
+  size_t temp_bytes = 0;
+  LBVH_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys, order_in, order, (size_t)un, 0u, 64u, stream));
+  LBVH_HIP(scratch.alloc(&sort_temp, temp_bytes > 0 ? temp_bytes : 16));
+
+  hipEvent_t ev0, ev1;
+  LBVH_HIP(hipEventCreate(&ev0));
+  LBVH_HIP(hipEventCreate(&ev1));
+  struct EventGuard {
+    hipEvent_t a, b;
+    ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+  } guard{ev0, ev1};
+  LBVH_HIP(hipEventRecord(ev0, stream));
+
+  KeyParams kp;
+  for (int k = 0; k < 3; k++) {
+    float ext = centroid_hi[k] - centroid_lo[k];
+    kp.lo[k] = centroid_lo[k];
+    kp.scale[k] = ext > 0.f ? 65535.0f / ext : 0.f;
+  }
+  kp.size_scale = max_diagonal > 0.f ? 65535.0f / max_diagonal : 0.f;
+  key_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_boxes, n, kp, keys_in, order_in);
+  LBVH_HIP(hipGetLastError());
+  LBVH_HIP(rocprim::radix_sort_pairs(sort_temp, temp_bytes, keys_in, keys, order_in, order, (size_t)un, 0u, 64u, stream));
+
+  // root: node 0 holds the whole sequence
+  const BuildRange root{0u, un};
+  const uint32_t one = 1u;
+  LBVH_HIP(hipMemcpyAsync(ranges, &root, sizeof root, hipMemcpyHostToDevice, stream));
+  LBVH_HIP(hipMemcpyAsync(counter, &one, sizeof one, hipMemcpyHostToDevice, stream));
+  std::vector<std::pair<uint32_t, uint32_t>> levels;
+  uint32_t begin = 0, end = 1;
+  int depth = 0;
+  while (begin < end) {
+    if (depth >= kMaxTreeDepth) return "internal: device tree deeper than the traversal stack allows";
+    split_level_kernel<<<blocks_for(end - begin), kBuildBlock, 0, stream>>>(keys, ranges, nodes_full, begin, end, depth, counter);
+    LBVH_HIP(hipGetLastError());
+    uint32_t total = 0;
+    LBVH_HIP(hipMemcpyAsync(&total, counter, sizeof total, hipMemcpyDeviceToHost, stream));
+    LBVH_HIP(hipStreamSynchronize(stream));
+    if (total < end || total >= un) return "internal: device tree node count out of range";
+    levels.emplace_back(begin, end);
+    begin = end;
+    end = total;
+    depth++;
+  }
+  const uint32_t n_built = end;
+  uint32_t *live = nullptr, *new_index = nullptr;
+  void* scan_temp = nullptr;
+  size_t scan_bytes = 0;
+  LBVH_HIP(scratch.alloc((void**)&live, n_built * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&new_index, n_built * sizeof(uint32_t)));
+  LBVH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, live, new_index, 0u, (size_t)n_built, rocprim::plus<uint32_t>(), stream));
+  LBVH_HIP(scratch.alloc(&scan_temp, scan_bytes > 0 ? scan_bytes : 16));
+  LBVH_HIP(hipMemsetAsync(live, 0, n_built * sizeof(uint32_t), stream));
+  LBVH_HIP(hipMemcpyAsync(live, &one, sizeof one, hipMemcpyHostToDevice, stream));  // the root
+  for (size_t l = levels.size(); l-- > 0;) {
+    fit_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
+        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live);
+    LBVH_HIP(hipGetLastError());
+  }
+  LBVH_HIP(rocprim::exclusive_scan(scan_temp, scan_bytes, live, new_index, 0u, (size_t)n_built, rocprim::plus<uint32_t>(), stream));
+  uint32_t last_index = 0, last_live = 0;
+  LBVH_HIP(hipMemcpyAsync(&last_index, new_index + (n_built - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  LBVH_HIP(hipMemcpyAsync(&last_live, live + (n_built - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  LBVH_HIP(hipStreamSynchronize(stream));
+  const uint32_t n_nodes = last_index + last_live;
+  if (n_nodes < 1 || n_nodes > n_built) return "internal: device tree compaction out of range";
+  PrimRec* prims = nullptr;
+  NodePair* nodes = nullptr;
+  LBVH_HIP(hipMalloc((void**)&prims, (size_t)un * sizeof(PrimRec)));
+  hipError_t e = hipMalloc((void**)&nodes, (size_t)n_nodes * sizeof(NodePair));
+  if (e != hipSuccess) { (void)hipFree(prims); return std::string("hipMalloc(nodes): ") + hipGetErrorString(e); }
+  compact_kernel<<<blocks_for(n_built), kBuildBlock, 0, stream>>>(nodes_full, live, new_index, n_built, nodes);
+  e = hipGetLastError();
+  if (e != hipSuccess) { (void)hipFree(prims); (void)hipFree(nodes); return std::string("compact_kernel: ") + hipGetErrorString(e); }
+  gather_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_prims_by_id, order, n, prims);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(ev1, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+  if (e != hipSuccess) {
+    (void)hipFree(prims);
+    (void)hipFree(nodes);
+    return std::string("device tree build: ") + hipGetErrorString(e);
+  }
+  out.nodes = nodes;
+  out.prims = prims;
+  out.n_nodes = (int32_t)n_nodes;
+  out.max_depth = (int32_t)levels.size();  // leaves of the deepest inner level
+  out.max_leaf = kMaxLeafSize;
+  out.build_ms = ms;
+  return std::string();
+}
+
+}  // namespace ptk

@@ -71,11 +71,15 @@ class PtkStats(C.Structure):
 class PtkSceneInfo(C.Structure):
     _fields_ = [("n_primitives", C.c_int32), ("n_lights", C.c_int32), ("n_nodes", C.c_int32), ("max_depth", C.c_int32),
                 ("max_leaf_size", C.c_int32), ("traversal_kind", C.c_int32), ("node_bytes", C.c_uint64),
-                ("prim_bytes", C.c_uint64), ("shading_bytes", C.c_uint64), ("texture_bytes", C.c_uint64)]
+                ("prim_bytes", C.c_uint64), ("shading_bytes", C.c_uint64), ("texture_bytes", C.c_uint64),
+                ("builder", C.c_int32), ("reserved", C.c_int32), ("upload_ms", C.c_double),
+                ("device_build_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
+
+BUILDERS = {"host": 0, "device": 1}  # PTK_BUILDER_HOST_SAH, PTK_BUILDER_DEVICE_LBVH
 
 RAY_DTYPE = np.dtype([("origin", np.float64, 3), ("direction", np.float64, 3)])
 HIT_DTYPE = np.dtype([("hit", np.int32), ("id", np.uint32), ("t", np.float32), ("point", np.float32, 3),
@@ -83,7 +87,7 @@ HIT_DTYPE = np.dtype([("hit", np.int32), ("id", np.uint32), ("t", np.float32), (
 assert HIT_DTYPE.itemsize == 52
 
 # every symbol include/ptk.h declares
-EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "ptk_scene_info_get", "ptk_set_camera",
+EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "ptk_upload_scene_ex", "ptk_scene_info_get", "ptk_set_camera",
            "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_read_accum", "ptk_read_display_u8", "ptk_synchronize",
            "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream"]
 
@@ -173,6 +177,7 @@ def load_library():
     L.ptk_last_error.argtypes = [vp]
     L.ptk_last_error.restype = C.c_char_p
     L.ptk_upload_scene.argtypes = [vp, C.POINTER(PtkSceneDesc)]
+    L.ptk_upload_scene_ex.argtypes = [vp, C.POINTER(PtkSceneDesc), C.c_int32]
     L.ptk_scene_info_get.argtypes = [vp, C.POINTER(PtkSceneInfo)]
     L.ptk_set_camera.argtypes = [vp, C.POINTER(PtkCamera)]
     L.ptk_set_flags.argtypes = [vp, C.POINTER(PtkFlags)]
@@ -219,9 +224,13 @@ class Context:
         except Exception:
             pass
 
-    def upload_scene(self, sd):
+    def upload_scene(self, sd, builder=None):
+        """builder: None (ptk_upload_scene: host tree unless PTK_BUILDER says otherwise), "host" or "device"."""
         desc, keep = make_scene_desc(sd)
-        self._check(self._L.ptk_upload_scene(self.h, C.byref(desc)), "ptk_upload_scene")
+        if builder is None:
+            self._check(self._L.ptk_upload_scene(self.h, C.byref(desc)), "ptk_upload_scene")
+        else:
+            self._check(self._L.ptk_upload_scene_ex(self.h, C.byref(desc), BUILDERS[builder]), "ptk_upload_scene_ex")
         del keep
 
     def scene_info(self):

@@ -13,10 +13,10 @@ BACKENDS = [pytest.param("host", id="hostcheck"), pytest.param("gpu", marks=pyte
 
 
 class GpuBackend:
-    def __init__(self, ctx, sd):
+    def __init__(self, ctx, sd, builder=None):
         self.ctx = ctx
         self.sd = sd
-        ctx.upload_scene(sd)
+        ctx.upload_scene(sd, builder)
         ctx.set_camera(sd.camera)
         ctx.set_flags(native.PtkFlags.defaults())
         ctx.bind_accum(None)
@@ -24,7 +24,8 @@ class GpuBackend:
     def info(self):
         i = self.ctx.scene_info()
         return dict(n_nodes=i["n_nodes"], max_depth=i["max_depth"], max_leaf=i["max_leaf_size"],
-                    n_lights=i["n_lights"], n_prims=i["n_primitives"])
+                    n_lights=i["n_lights"], n_prims=i["n_primitives"], builder=i["builder"],
+                    upload_ms=i["upload_ms"], device_build_ms=i["device_build_ms"])
 
     def intersect(self, rays):
         self.ctx.reset_stats()

@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(native.PtkFlags) == 24
     assert C.sizeof(native.PtkRenderParams) == 11 * 4
     assert C.sizeof(native.PtkStats) == 5 * 8 + 2 * 8 + 8
-    assert C.sizeof(native.PtkSceneInfo) == 6 * 4 + 4 * 8
+    assert C.sizeof(native.PtkSceneInfo) == 6 * 4 + 4 * 8 + 2 * 4 + 2 * 8
     assert native.RAY_DTYPE.itemsize == 48 and native.HIT_DTYPE.itemsize == 52
 
 

@@ -1,0 +1,96 @@
+"""The tree built on the GPU (ptk_upload_scene_ex, PTK_BUILDER_DEVICE_LBVH) must answer every query like the
+host-built tree does: the closest hit of a ray does not depend on the tree.  Checked against the oracle on
+the small scenes, against the host-built tree on a large one, and on inputs that force the builder's
+fallbacks (equal sort keys, tiny scenes)."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from pathtracer_amd import scenes
+from tests import parity, raygen
+from tests.backends import GpuBackend, scene
+
+pytestmark = pytest.mark.gpu
+
+MAX_TREE_DEPTH = 25  # ptk_layout.h: kStackDepth - 2
+
+
+def _f32_rays(rays):
+    return np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("scene_name", ["mesh", "glass", "envmap"])
+def test_device_tree_ids_exact(scene_name, gpu_ctx):
+    sd = scene(scene_name)
+    o = orc.OracleScene(sd)
+    b = GpuBackend(gpu_ctx, sd, builder="device")
+    info = b.info()
+    assert info["builder"] == 1 and info["device_build_ms"] > 0.0
+    assert 1 <= info["max_depth"] <= MAX_TREE_DEPTH and info["max_leaf"] <= 4
+    assert info["n_prims"] / 4 - 1 <= info["n_nodes"] < info["n_prims"]
+    rays = _f32_rays(np.concatenate([raygen.interior_rays(30000, 42), raygen.camera_like_rays(15000, 43)]))
+    ref, cref = o.intersect(rays)
+    got, cgot = b.intersect(rays)
+    c = parity.classify_hits(sd, rays, ref, got)
+    print(scene_name, info, c, cref, cgot)
+    assert c["unexplained"] == 0, c
+    assert c["tie"] + c["near"] + c["ref_miss"] + c["graze"] + c["cond"] <= max(3, 1e-4 * c["n"]), c
+    assert c["max_rel_t"] <= 1e-5, c
+    rec = parity.check_hit_records(ref, got)
+    assert rec["point"] < 1e-5 and rec["uv"] < 1e-4 and rec["material_mismatch"] == 0 and rec["normal"] < 1e-5
+    # still no more work per query than the reference's own tree
+    assert cgot["prim_tests"] <= cref["prim_tests"] and cgot["box_tests"] <= cref["box_tests"]
+
+
+def test_device_tree_agrees_with_host_tree_on_a_large_mesh(gpu_ctx):
+    sd = scenes.cornell_with_mesh(6, 96, 96)  # 81 920 triangles + the box
+    rays = _f32_rays(np.concatenate([raygen.interior_rays(200000, 5), raygen.camera_like_rays(100000, 6)]))
+    host = GpuBackend(gpu_ctx, sd, builder="host")
+    assert host.info()["builder"] == 0
+    h_hits, h_cnt = host.intersect(rays)
+    img_h, _ = host.render(16, 3, seed=3)
+    dev = GpuBackend(gpu_ctx, sd, builder="device")
+    info = dev.info()
+    assert info["builder"] == 1 and info["max_depth"] <= MAX_TREE_DEPTH
+    d_hits, d_cnt = dev.intersect(rays)
+    img_d, _ = dev.render(16, 3, seed=3)
+    print(info, h_cnt, d_cnt)
+    assert (h_hits["hit"] == d_hits["hit"]).mean() > 1 - 1e-5
+    both = (h_hits["hit"] == 1) & (d_hits["hit"] == 1)
+    # the same primitive up to exact ties in distance (shared edges), the same distance always
+    assert (h_hits["id"][both] != d_hits["id"][both]).mean() < 1e-4
+    assert np.allclose(h_hits["t"][both], d_hits["t"][both], rtol=1e-6, atol=0)
+    # the same random numbers meet the same surfaces: the frames differ only where a tie went the other way
+    assert np.abs(img_h - img_d).mean() < 2e-3 * max(img_h.mean(), 1e-6)
+    assert np.median(np.abs(img_h - img_d)) == 0.0
+
+
+def test_equal_keys_and_tiny_scenes(gpu_ctx):
+    """5 000 copies of one triangle have one sort key: every split is a median split, the depth limit holds and
+    a ray meets the copy with the lowest id that the traversal tests first or any other (equal distance).
+    A scene below the device builder's minimum size gets the host's tree."""
+    sd = scenes.SceneData()
+    m = sd.add_material(scenes.Material())
+    tri = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.float64)
+    sd.add_triangles(np.repeat(tri, 5000, axis=0), np.tile([0, 0, 1.0], (5000, 3, 1)), np.zeros((5000, 3, 2)), m)
+    sd.camera = scenes.CameraDesc(16, 16)
+    b = GpuBackend(gpu_ctx, sd, builder="device")
+    info = b.info()
+    assert info["builder"] == 1 and info["max_depth"] <= MAX_TREE_DEPTH
+    rays = _f32_rays(raygen.interior_rays(2000, 3, lo=(-2, -2, 3), hi=(2, 2, 6)))
+    rays[:, 3:] = np.array([0.0, 0.0, -1.0]) + 0.2 * rays[:, 3:]
+    got, _ = b.intersect(rays)
+    o = orc.OracleScene(sd)
+    ref, _ = o.intersect(rays)
+    # the reference's tree rejects a flat single-triangle box; compare against geometry instead
+    t_plane = -rays[:, 2] / rays[:, 5]
+    p = rays[:, :3] + t_plane[:, None] * rays[:, 3:]
+    inside = (p[:, 1] > -1 + 1e-4) & (p[:, 1] < 1 - 1e-4) & (np.abs(p[:, 0]) < (1 - p[:, 1]) / 2 - 1e-4)
+    assert (got["hit"][inside] == 1).all() and np.allclose(got["t"][inside], t_plane[inside], rtol=1e-5)
+    outside = (p[:, 1] < -1 - 1e-4) | (p[:, 1] > 1 + 1e-4) | (np.abs(p[:, 0]) > (1 - p[:, 1]) / 2 + 1e-4)
+    assert (got["hit"][outside] == 0).all()
+    del ref
+
+    small = scene("cornell_pinhole")
+    b = GpuBackend(gpu_ctx, small, builder="device")
+    assert b.info()["builder"] == 0 and b.info()["device_build_ms"] == 0.0

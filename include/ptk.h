@@ -154,7 +154,7 @@ typedef struct {
   int32_t n_primitives, n_lights, n_nodes, max_depth, max_leaf_size, traversal_kind;
   uint64_t node_bytes, prim_bytes, shading_bytes, texture_bytes;
   int32_t builder;         /* PTK_BUILDER_* that built the tree in use */
-  int32_t reserved;
+  int32_t tree_from_cache; /* 1: the host tree was read from the directory PTK_BVH_CACHE names */
   double upload_ms;        /* host wall time of the ptk_upload_scene call (flattening, tree, copies) */
   double device_build_ms;  /* device time of the tree build; 0 for a host-built tree */
 } ptk_scene_info;
@@ -177,7 +177,8 @@ int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene);
  *                            primitives are built on the host either way.
  * Which tree is used never changes the closest hit of a ray (apart from exact ties in distance).
  * ptk_upload_scene takes the builder from the environment variable PTK_BUILDER (host | device),
- * host when unset. */
+ * host when unset.  With PTK_BVH_CACHE naming a directory, host-built trees are kept there, keyed by a
+ * hash of the geometry, and read back (after a full validity check) instead of being rebuilt. */
 #define PTK_BUILDER_HOST_SAH 0
 #define PTK_BUILDER_DEVICE_LBVH 1
 int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder);

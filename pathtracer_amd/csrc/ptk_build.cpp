@@ -10,6 +10,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <unistd.h>
 
 namespace ptk {
 
@@ -240,6 +241,115 @@ void set_child_box(NodePair& n, int which, const Box& b)
   else { n.xy1 = f4{b.lo[0], b.hi[0], b.lo[1], b.hi[1]}; n.zz.z = b.lo[2]; n.zz.w = b.hi[2]; }
 }
 
+// ---- on-disk tree cache ---------------------------------------------------------------------------
+struct CacheKey {
+  uint64_t a, b;
+};
+
+// Two independent multiply-xorshift hashes over the boxes (the only input of the tree) and the limits
+// that shape it.
+CacheKey hash_boxes(const std::vector<Box>& boxes)
+{
+  uint64_t h0 = 0x243F6A8885A308D3ull ^ (uint64_t)boxes.size(), h1 = 0x13198A2E03707344ull + (uint64_t)boxes.size();
+  auto mix = [&](uint64_t w) {
+    h0 = (h0 ^ w) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
+    h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
+  };
+  mix(((uint64_t)kMaxLeafSize << 32) | (uint64_t)kMaxTreeDepth);
+  mix(((uint64_t)kBins << 32) | 3u /* builder revision: change when the builder's decisions change */);
+  uint32_t ic, tc;
+  std::memcpy(&ic, &kIntersectCost, 4); std::memcpy(&tc, &kTraversalCost, 4);
+  mix(((uint64_t)ic << 32) | tc);
+  static_assert(sizeof(Box) == 24, "Box is six floats");
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(boxes.data());
+  for (size_t i = 0, n = boxes.size() * 3; i < n; i++) mix(w[i]);
+  return CacheKey{h0, h1};
+}
+
+struct CacheHeader {
+  char magic[8];  // "PTKBVH1\0"
+  uint64_t key_a, key_b;
+  int32_t n_prims, n_nodes, max_depth, max_leaf;
+};
+
+std::string cache_path(const char* dir, CacheKey k)
+{
+  char name[64];
+  snprintf(name, sizeof name, "/ptkbvh-%016llx%016llx.bin", (unsigned long long)k.a, (unsigned long long)k.b);
+  return std::string(dir) + name;
+}
+
+// Everything the traversal relies on is checked: a damaged file must not send a kernel out of bounds.
+bool tree_is_valid(const std::vector<NodePair>& nodes, const std::vector<uint32_t>& order, int32_t n_prims, int32_t max_depth,
+                   int32_t max_leaf)
+{
+  if (nodes.empty() || (int32_t)order.size() != n_prims || max_depth > kMaxTreeDepth || max_leaf > kMaxLeafSize) return false;
+  std::vector<uint8_t> seen((size_t)n_prims, 0);
+  for (uint32_t id : order) {
+    if (id >= (uint32_t)n_prims || seen[id]) return false;
+    seen[id] = 1;
+  }
+  std::vector<uint8_t> visited(nodes.size(), 0);
+  std::vector<uint8_t> covered((size_t)n_prims, 0);
+  struct Todo { int32_t node; int32_t depth; };
+  std::vector<Todo> stack{{0, 0}};
+  while (!stack.empty()) {
+    Todo t = stack.back(); stack.pop_back();
+    if (t.node < 0 || (size_t)t.node >= nodes.size() || visited[t.node] || t.depth + 1 > max_depth) return false;
+    visited[t.node] = 1;
+    for (int32_t link : {nodes[t.node].child0, nodes[t.node].child1}) {
+      if (link >= 0) { stack.push_back({link, t.depth + 1}); continue; }
+      uint32_t leaf = ~(uint32_t)link, first = leaf >> 3, count = (leaf & 7u) + 1u;
+      if ((int32_t)count > max_leaf || (uint64_t)first + count > (uint64_t)n_prims) return false;
+      for (uint32_t i = first; i < first + count; i++) {
+        if (covered[i]) return false;
+        covered[i] = 1;
+      }
+    }
+  }
+  for (uint8_t c : covered) if (!c) return false;
+  return true;
+}
+
+bool cache_load(const std::string& path, CacheKey key, int32_t n_prims, std::vector<NodePair>& nodes, std::vector<uint32_t>& order,
+                int32_t& max_depth, int32_t& max_leaf)
+{
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  CacheHeader h;
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH1", 8) == 0 && h.key_a == key.a &&
+            h.key_b == key.b && h.n_prims == n_prims && h.n_nodes >= 1 && h.n_nodes <= n_prims + 1;
+  if (ok) {
+    nodes.resize((size_t)h.n_nodes);
+    order.resize((size_t)n_prims);
+    ok = std::fread(nodes.data(), sizeof(NodePair), nodes.size(), f) == nodes.size() &&
+         std::fread(order.data(), sizeof(uint32_t), order.size(), f) == order.size() && std::fgetc(f) == EOF;
+  }
+  std::fclose(f);
+  if (ok) ok = tree_is_valid(nodes, order, n_prims, h.max_depth, h.max_leaf);
+  if (ok) { max_depth = h.max_depth; max_leaf = h.max_leaf; }
+  return ok;
+}
+
+void cache_store(const std::string& path, CacheKey key, const std::vector<NodePair>& nodes, const std::vector<uint32_t>& order,
+                 int32_t max_depth, int32_t max_leaf)
+{
+  // written beside the final name and renamed, so that a reader never sees half a file
+  std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  CacheHeader h;
+  std::memset(&h, 0, sizeof h);
+  std::memcpy(h.magic, "PTKBVH1", 8);
+  h.key_a = key.a; h.key_b = key.b;
+  h.n_prims = (int32_t)order.size(); h.n_nodes = (int32_t)nodes.size();
+  h.max_depth = max_depth; h.max_leaf = max_leaf;
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(nodes.data(), sizeof(NodePair), nodes.size(), f) == nodes.size() &&
+            std::fwrite(order.data(), sizeof(uint32_t), order.size(), f) == order.size();
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+
 }  // namespace
 
 SceneView HostScene::host_view() const
@@ -324,15 +434,23 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   std::memset(by_id.data(), 0, by_id.size() * sizeof(PrimRec));
   std::vector<Box> boxes(n);
   double max_abs = 1.0;
-  for (int i = 0; i < d.n_triangles; i++) {
+  // Triangles are independent: large scenes are converted by several threads, each on a contiguous share,
+  // and the shares' lights are appended in share order so that the light list stays in id order.
+  struct Share {
+    std::string error;
+    double max_abs = 1.0;
+    std::vector<LightRec> lights;
+  };
+  auto convert = [&](int lo_i, int hi_i, Share& sh) {
+  for (int i = lo_i; i < hi_i; i++) {
     const double* p = d.tri_pos + 9 * (size_t)i;
     const double* nr = d.tri_nrm + 9 * (size_t)i;
     const double* uv = d.tri_uv + 6 * (size_t)i;
     int mat = d.tri_material[i];
-    if (mat < 0 || mat >= d.n_materials) return "triangle material index out of range";
+    if (mat < 0 || mat >= d.n_materials) { sh.error = "triangle material index out of range"; return; }
     for (int k = 0; k < 9; k++) {
-      if (!std::isfinite(p[k])) return "non-finite triangle vertex";
-      max_abs = std::max(max_abs, std::fabs(p[k]));
+      if (!std::isfinite(p[k])) { sh.error = "non-finite triangle vertex"; return; }
+      sh.max_abs = std::max(sh.max_abs, std::fabs(p[k]));
     }
     ShadeRec& s = out.shade[i];
     for (int k = 0; k < 3; k++) { s.n0[k] = (float)nr[k]; s.n1[k] = (float)nr[3 + k]; s.n2[k] = (float)nr[6 + k]; }
@@ -362,7 +480,28 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
         l.n0[k] = (float)nr[k]; l.n1[k] = (float)nr[3 + k]; l.n2[k] = (float)nr[6 + k];
         l.emission[k] = out.materials[mat].emission[k];
       }
-      out.lights.push_back(l);
+      sh.lights.push_back(l);
+    }
+  }
+  };
+  {
+    int shares = 1;
+    if (d.n_triangles >= 65536) {
+      shares = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char* e = getenv("PTK_BUILD_THREADS")) shares = std::max(1, atoi(e));
+    }
+    std::vector<Share> share(shares);
+    std::vector<std::thread> workers;
+    for (int t = 1; t < shares; t++) {
+      int lo_i = (int)((int64_t)d.n_triangles * t / shares), hi_i = (int)((int64_t)d.n_triangles * (t + 1) / shares);
+      workers.emplace_back([&, lo_i, hi_i, t] { convert(lo_i, hi_i, share[t]); });
+    }
+    convert(0, (int)((int64_t)d.n_triangles / shares), share[0]);
+    for (auto& w : workers) w.join();
+    for (auto& sh : share) {
+      if (!sh.error.empty()) return sh.error;
+      max_abs = std::max(max_abs, sh.max_abs);
+      out.lights.insert(out.lights.end(), sh.lights.begin(), sh.lights.end());
     }
   }
   for (int j = 0; j < d.n_spheres; j++) {
@@ -450,6 +589,23 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     fprintf(stderr, "[ptk build] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
     t0 = t1;
   };
+  const char* cache_dir = getenv("PTK_BVH_CACHE");
+  std::string cache_file;
+  CacheKey cache_key{0, 0};
+  if (cache_dir && *cache_dir && n >= kDeviceBuildMin) {
+    cache_key = hash_boxes(boxes);
+    cache_file = cache_path(cache_dir, cache_key);
+    std::vector<uint32_t> order;
+    if (cache_load(cache_file, cache_key, n, out.nodes, order, out.max_depth, out.max_leaf)) {
+      out.prims.resize((size_t)n);
+      for (int i = 0; i < n; i++) out.prims[i] = by_id[order[i]];
+      out.tree_from_cache = true;
+      lap("tree read from the cache");
+      return std::string();
+    }
+    out.nodes.clear();
+    lap("cache miss");
+  }
   Builder bld(boxes);
   lap("centroids");
   // 16 = one GPU's share of a node's host cores (std::thread::hardware_concurrency() sees the whole node)
@@ -521,6 +677,12 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     for (auto r = mine.rbegin(); r != mine.rend(); ++r) todo.push_back(*r);
   }
   lap("flatten");
+  if (!cache_file.empty()) {
+    std::vector<uint32_t> order((size_t)n);
+    for (int i = 0; i < n; i++) order[i] = as_uint(out.prims[i].c.y);
+    cache_store(cache_file, cache_key, out.nodes, order, out.max_depth, out.max_leaf);
+    lap("cache written");
+  }
   return std::string();
 }
 

@@ -32,6 +32,7 @@ struct HostScene {
   int32_t n_triangles = 0;
   int32_t max_depth = 0;
   int32_t max_leaf = 0;
+  bool tree_from_cache = false;  // the tree was read from the on-disk cache instead of being built
   // Filled instead of `nodes` when the tree is left to the device builder: `prims` is then in id order and
   // these are the padded boxes (lo.xyz, hi.xyz per primitive) the tree has to be built over.
   std::vector<float> prim_boxes;
@@ -45,6 +46,11 @@ struct HostScene {
 // Returns an empty string on success, otherwise the reason the description was rejected.
 // with_tree = false: everything except the tree (see HostScene::prim_boxes); scenes of fewer than
 // kDeviceBuildMin primitives get their tree here regardless.
+//
+// Tree cache: with the environment variable PTK_BVH_CACHE naming a directory, a host-built tree is stored
+// there under a 128-bit hash of the primitives' boxes and the builder's limits, and a later build of the
+// same geometry reads it back instead of building (files are checked in full before use: sizes, link
+// ranges, depth, and that the leaf order is a permutation).
 constexpr int kDeviceBuildMin = 64;
 std::string build_host_scene(const ptk_scene_desc& desc, HostScene& out, bool with_tree = true);
 

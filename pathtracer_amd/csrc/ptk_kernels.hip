@@ -669,7 +669,7 @@ int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
   out->shading_bytes = h.shade.size() * sizeof(ShadeRec) + h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec);
   out->texture_bytes = ctx->texel_bytes;
   out->builder = ctx->builder;
-  out->reserved = 0;
+  out->tree_from_cache = ctx->host.tree_from_cache ? 1 : 0;
   out->upload_ms = ctx->upload_ms;
   out->device_build_ms = ctx->tree_ms;
   return PTK_OK;

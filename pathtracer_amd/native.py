@@ -72,7 +72,7 @@ class PtkSceneInfo(C.Structure):
     _fields_ = [("n_primitives", C.c_int32), ("n_lights", C.c_int32), ("n_nodes", C.c_int32), ("max_depth", C.c_int32),
                 ("max_leaf_size", C.c_int32), ("traversal_kind", C.c_int32), ("node_bytes", C.c_uint64),
                 ("prim_bytes", C.c_uint64), ("shading_bytes", C.c_uint64), ("texture_bytes", C.c_uint64),
-                ("builder", C.c_int32), ("reserved", C.c_int32), ("upload_ms", C.c_double),
+                ("builder", C.c_int32), ("tree_from_cache", C.c_int32), ("upload_ms", C.c_double),
                 ("device_build_ms", C.c_double)]
 
     def as_dict(self):

@@ -64,10 +64,10 @@ class HostCheck:
             pass
 
     def info(self):
-        out = np.zeros(5, np.int32)
+        out = np.zeros(6, np.int32)
         lib().hc_info(self.h, out.ctypes.data)
         return dict(n_nodes=int(out[0]), max_depth=int(out[1]), max_leaf=int(out[2]), n_lights=int(out[3]),
-                    n_prims=int(out[4]))
+                    n_prims=int(out[4]), tree_from_cache=int(out[5]))
 
     def intersect(self, rays):
         rays = np.asarray(rays, np.float64).reshape(-1, 6)

@@ -52,11 +52,12 @@ void* hc_create(const ptk_scene_desc* d)
 const char* hc_error(void* h) { return ((Check*)h)->err.c_str(); }
 void hc_destroy(void* h) { delete (Check*)h; }
 
-void hc_info(void* h, int32_t* out /* n_nodes, max_depth, max_leaf, n_lights, n_prims */)
+void hc_info(void* h, int32_t* out /* n_nodes, max_depth, max_leaf, n_lights, n_prims, tree_from_cache */)
 {
   Check* c = (Check*)h;
   out[0] = (int32_t)c->host.nodes.size(); out[1] = c->host.max_depth; out[2] = c->host.max_leaf;
   out[3] = (int32_t)c->host.lights.size(); out[4] = c->host.n_prims;
+  out[5] = c->host.tree_from_cache ? 1 : 0;
 }
 
 // returns the deepest stack use seen

@@ -172,3 +172,45 @@ def test_pt_command_line_matches_oracle(tmp_path, with_spheres):
     # usage message and a missing config are errors, as in the reference
     assert subprocess.run([PT], capture_output=True).returncode == 1
     assert subprocess.run([PT, str(tmp_path / "nope.json"), str(out)], capture_output=True).returncode == 1
+
+
+def test_tree_cache_round_trip(tmp_path, monkeypatch):
+    """PTK_BVH_CACHE: the second build of the same geometry reads the stored tree (same nodes, same hits); a
+    damaged file is rejected by the validity check and rebuilt; other geometry gets its own file."""
+    import numpy as np
+    from tests import raygen
+    from tests.backends import HostBackend, scene
+    from pathtracer_amd import scenes
+
+    monkeypatch.setenv("PTK_BVH_CACHE", str(tmp_path))
+    sd = scene("mesh")
+    rays = np.asarray(raygen.interior_rays(5000, 9), np.float64).astype(np.float32).astype(np.float64)
+    first = HostBackend(sd)
+    assert first.info()["tree_from_cache"] == 0
+    files = list(tmp_path.glob("ptkbvh-*.bin"))
+    assert len(files) == 1
+    hits1, _ = first.intersect(rays)
+    second = HostBackend(sd)
+    assert second.info()["tree_from_cache"] == 1
+    assert second.info()["n_nodes"] == first.info()["n_nodes"] and second.info()["max_depth"] == first.info()["max_depth"]
+    hits2, _ = second.intersect(rays)
+    assert (hits1["id"] == hits2["id"]).all() and (hits1["t"] == hits2["t"]).all()
+
+    # corrupt one child link in the middle of the node array: the file must be refused, the tree rebuilt
+    raw = bytearray(files[0].read_bytes())
+    header = 8 + 16 + 16
+    link = header + 64 * 10 + 48
+    raw[link:link + 4] = (0x7fffff00).to_bytes(4, "little")
+    files[0].write_bytes(bytes(raw))
+    third = HostBackend(sd)
+    assert third.info()["tree_from_cache"] == 0
+    hits3, _ = third.intersect(rays)
+    assert (hits1["id"] == hits3["id"]).all()
+    # a truncated file likewise
+    files[0].write_bytes(files[0].read_bytes()[:1000])
+    assert HostBackend(sd).info()["tree_from_cache"] == 0
+
+    other = scenes.cornell_with_mesh(3, 32, 32)
+    assert HostBackend(other).info()["tree_from_cache"] == 0
+    assert len(list(tmp_path.glob("ptkbvh-*.bin"))) == 2
+    assert not list(tmp_path.glob("*.tmp*"))

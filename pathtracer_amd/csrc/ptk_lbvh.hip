@@ -14,15 +14,14 @@
 //   4. fit_level_kernel, deepest level first: child boxes from the primitives' boxes (leaves) or from
 //      the child's own record (inner nodes); subtrees of at most kMaxLeafSize primitives are merged into one
 //      leaf where the surface-area heuristic prefers that.
-//   5. compact_kernel: the nodes still in use are packed (prefix sum over the in-use flags) and their links
-//      renumbered; gather_kernel: primitive records into leaf order.
+//   5. number_level_kernel, top level first, gives the nodes still in use their final depth-first positions
+//      (from the subtree sizes the fitting pass left); compact_kernel moves them there and renumbers the links; gather_kernel: primitive records into leaf order.
 #include "ptk_lbvh.h"
 
 #include <cstring>  // rocprim headers use memset without including it
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 namespace ptk {
 
@@ -175,7 +174,8 @@ __device__ inline DevBox child_box(int32_t& link, const float* __restrict__ boxe
 // Nodes [begin, end) are one level; every deeper level has been fitted already.
 __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __restrict__ boxes,
                                                                 const uint32_t* __restrict__ order, NodePair* nodes,
-                                                                uint32_t begin, uint32_t end, uint32_t* __restrict__ live)
+                                                                uint32_t begin, uint32_t end, uint32_t* __restrict__ live,
+                                                                uint32_t* __restrict__ subtree)
 {
   uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= end) return;
@@ -186,9 +186,25 @@ __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __r
   // A node merged into a leaf has only leaves below it, so whatever an inner link still points at is in use.
   if (c0 >= 0) live[c0] = 1u;
   if (c1 >= 0) live[c1] = 1u;
+  subtree[i] = 1u + (c0 >= 0 ? subtree[c0] : 0u) + (c1 >= 0 ? subtree[c1] : 0u);  // inner nodes in use from here down
   nodes[i].xy0 = f4{b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1]};
   nodes[i].xy1 = f4{b1.lo[0], b1.hi[0], b1.lo[1], b1.hi[1]};
   nodes[i].zz = f4{b0.lo[2], b0.hi[2], b1.lo[2], b1.hi[2]};
+}
+
+// Final positions, top-down: depth-first order (a node, its first child's whole subtree, then the second
+// child's), which keeps the lower levels of every subtree together in memory.
+__global__ __launch_bounds__(kBuildBlock) void number_level_kernel(const NodePair* __restrict__ nodes,
+                                                                   const uint32_t* __restrict__ live,
+                                                                   const uint32_t* __restrict__ subtree, uint32_t begin,
+                                                                   uint32_t end, uint32_t* new_index)
+{
+  uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i >= end || !live[i]) return;
+  const uint32_t at = new_index[i];
+  const int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
+  if (c0 >= 0) new_index[c0] = at + 1u;
+  if (c1 >= 0) new_index[c1] = at + 1u + (c0 >= 0 ? subtree[c0] : 0u);
 }
 
 // Nodes in use move to their final, dense positions; inner links follow.
@@ -301,26 +317,26 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
     depth++;
   }
   const uint32_t n_built = end;
-  uint32_t *live = nullptr, *new_index = nullptr;
-  void* scan_temp = nullptr;
-  size_t scan_bytes = 0;
+  uint32_t *live = nullptr, *new_index = nullptr, *subtree = nullptr;
   LBVH_HIP(scratch.alloc((void**)&live, n_built * sizeof(uint32_t)));
   LBVH_HIP(scratch.alloc((void**)&new_index, n_built * sizeof(uint32_t)));
-  LBVH_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, live, new_index, 0u, (size_t)n_built, rocprim::plus<uint32_t>(), stream));
-  LBVH_HIP(scratch.alloc(&scan_temp, scan_bytes > 0 ? scan_bytes : 16));
+  LBVH_HIP(scratch.alloc((void**)&subtree, n_built * sizeof(uint32_t)));
   LBVH_HIP(hipMemsetAsync(live, 0, n_built * sizeof(uint32_t), stream));
   LBVH_HIP(hipMemcpyAsync(live, &one, sizeof one, hipMemcpyHostToDevice, stream));  // the root
+  LBVH_HIP(hipMemsetAsync(new_index, 0, sizeof(uint32_t), stream));                 // stays node 0
   for (size_t l = levels.size(); l-- > 0;) {
     fit_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
-        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live);
+        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree);
     LBVH_HIP(hipGetLastError());
   }
-  LBVH_HIP(rocprim::exclusive_scan(scan_temp, scan_bytes, live, new_index, 0u, (size_t)n_built, rocprim::plus<uint32_t>(), stream));
-  uint32_t last_index = 0, last_live = 0;
-  LBVH_HIP(hipMemcpyAsync(&last_index, new_index + (n_built - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  LBVH_HIP(hipMemcpyAsync(&last_live, live + (n_built - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  for (size_t l = 0; l < levels.size(); l++) {
+    number_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
+        nodes_full, live, subtree, levels[l].first, levels[l].second, new_index);
+    LBVH_HIP(hipGetLastError());
+  }
+  uint32_t n_nodes = 0;
+  LBVH_HIP(hipMemcpyAsync(&n_nodes, subtree, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   LBVH_HIP(hipStreamSynchronize(stream));
-  const uint32_t n_nodes = last_index + last_live;
   if (n_nodes < 1 || n_nodes > n_built) return "internal: device tree compaction out of range";
   PrimRec* prims = nullptr;
   NodePair* nodes = nullptr;

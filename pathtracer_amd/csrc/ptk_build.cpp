@@ -235,11 +235,7 @@ inline float f_up(double x)
 
 int32_t leaf_code(int first, int count) { return (int32_t) ~(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
 
-void set_child_box(NodePair& n, int which, const Box& b)
-{
-  if (which == 0) { n.xy0 = f4{b.lo[0], b.hi[0], b.lo[1], b.hi[1]}; n.zz.x = b.lo[2]; n.zz.y = b.hi[2]; }
-  else { n.xy1 = f4{b.lo[0], b.hi[0], b.lo[1], b.hi[1]}; n.zz.z = b.lo[2]; n.zz.w = b.hi[2]; }
-}
+void set_child_box(NodePair& n, int which, const Box& b, const BoxGrid& g) { set_child_box(n, which, b.lo, b.hi, g); }
 
 // ---- on-disk tree cache ---------------------------------------------------------------------------
 struct CacheKey {
@@ -256,7 +252,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
     h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
   };
   mix(((uint64_t)kMaxLeafSize << 32) | (uint64_t)kMaxTreeDepth);
-  mix(((uint64_t)kBins << 32) | 3u /* builder revision: change when the builder's decisions change */);
+  mix(((uint64_t)kBins << 32) | 4u /* builder revision: change when the builder's decisions change */);
   uint32_t ic, tc;
   std::memcpy(&ic, &kIntersectCost, 4); std::memcpy(&tc, &kTraversalCost, 4);
   mix(((uint64_t)ic << 32) | tc);
@@ -267,7 +263,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
 }
 
 struct CacheHeader {
-  char magic[8];  // "PTKBVH1\0"
+  char magic[8];  // "PTKBVH2\0"
   uint64_t key_a, key_b;
   int32_t n_prims, n_nodes, max_depth, max_leaf;
 };
@@ -317,7 +313,7 @@ bool cache_load(const std::string& path, CacheKey key, int32_t n_prims, std::vec
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   CacheHeader h;
-  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH1", 8) == 0 && h.key_a == key.a &&
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH2", 8) == 0 && h.key_a == key.a &&
             h.key_b == key.b && h.n_prims == n_prims && h.n_nodes >= 1 && h.n_nodes <= n_prims + 1;
   if (ok) {
     nodes.resize((size_t)h.n_nodes);
@@ -340,7 +336,7 @@ void cache_store(const std::string& path, CacheKey key, const std::vector<NodePa
   if (!f) return;
   CacheHeader h;
   std::memset(&h, 0, sizeof h);
-  std::memcpy(h.magic, "PTKBVH1", 8);
+  std::memcpy(h.magic, "PTKBVH2", 8);
   h.key_a = key.a; h.key_b = key.b;
   h.n_prims = (int32_t)order.size(); h.n_nodes = (int32_t)nodes.size();
   h.max_depth = max_depth; h.max_leaf = max_leaf;
@@ -365,6 +361,7 @@ SceneView HostScene::host_view() const
   v.texels = texels.data();
   v.n_prims = n_prims;
   v.n_triangles = n_triangles;
+  v.grid = grid;
   v.n_lights = (int32_t)lights.size();
   v.n_nodes = (int32_t)nodes.size();
   v.n_materials = (int32_t)materials.size();
@@ -539,8 +536,14 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   // Boxes are widened by a few ulps of the largest coordinate: the fp32 slab test and the fp32
   // triangle test round independently, and a hit on a box face must not be lost to that.
   const float pad = (float)(max_abs * 2e-6);
-  for (auto& b : boxes)
+  Box scene_box;
+  scene_box.reset();
+  for (auto& b : boxes) {
     for (int a = 0; a < 3; a++) { b.lo[a] -= pad; b.hi[a] += pad; }
+    scene_box.grow(b);
+  }
+  if (n == 0) { for (int a = 0; a < 3; a++) { scene_box.lo[a] = 0.f; scene_box.hi[a] = 1.f; } }
+  out.grid = make_box_grid(scene_box.lo, scene_box.hi);
 
   // --- background --------------------------------------------------------------
   out.background_texture = d.background_texture < 0 ? -1 : d.background_texture;
@@ -551,9 +554,8 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   if (n == 0) {
     NodePair e;
     std::memset(&e, 0, sizeof e);
-    Box far_box;
-    for (int a = 0; a < 3; a++) far_box.lo[a] = far_box.hi[a] = 1e30f;
-    set_child_box(e, 0, far_box); set_child_box(e, 1, far_box);
+    // both children: the one all-zero primitive record (a degenerate triangle that no ray hits)
+    set_child_box(e, 0, scene_box, out.grid); set_child_box(e, 1, scene_box, out.grid);
     e.child0 = e.child1 = leaf_code(0, 1);
     out.nodes.push_back(e);
     out.prims.assign(1, by_id[0]);
@@ -651,10 +653,10 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   if (bld.nodes[0].left < 0) {  // the whole scene is one leaf
     NodePair e;
     std::memset(&e, 0, sizeof e);
-    Box far_box;
-    for (int a = 0; a < 3; a++) far_box.lo[a] = far_box.hi[a] = 1e30f;
-    set_child_box(e, 0, bld.nodes[0].box);
-    set_child_box(e, 1, far_box);
+    // grid positions cannot express "nowhere", so the second child repeats the first: its primitives are
+    // tested twice, and the second time none of them is strictly closer
+    set_child_box(e, 0, bld.nodes[0].box, out.grid);
+    set_child_box(e, 1, bld.nodes[0].box, out.grid);
     e.child0 = e.child1 = leaf_code(0, bld.nodes[0].count);
     out.nodes.push_back(e);
     return std::string();
@@ -671,8 +673,8 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     int32_t c0 = child_code(bn.left, mine);
     int32_t c1 = child_code(bn.right, mine);
     NodePair& np = out.nodes[it.out_node];
-    set_child_box(np, 0, bld.nodes[bn.left].box);
-    set_child_box(np, 1, bld.nodes[bn.right].box);
+    set_child_box(np, 0, bld.nodes[bn.left].box, out.grid);
+    set_child_box(np, 1, bld.nodes[bn.right].box, out.grid);
     np.child0 = c0; np.child1 = c1;
     for (auto r = mine.rbegin(); r != mine.rend(); ++r) todo.push_back(*r);
   }

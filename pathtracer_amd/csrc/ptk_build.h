@@ -30,6 +30,7 @@ struct HostScene {
   float background_color[3] = {-1.f, -1.f, -1.f};
   int32_t n_prims = 0;
   int32_t n_triangles = 0;
+  BoxGrid grid = {{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};  // see NodePair
   int32_t max_depth = 0;
   int32_t max_leaf = 0;
   bool tree_from_cache = false;  // the tree was read from the on-disk cache instead of being built

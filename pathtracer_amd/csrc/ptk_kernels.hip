@@ -71,19 +71,30 @@ constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phas
 #endif
 constexpr int kDescendMin = PTK_DESCEND_MIN;
 
+// Layout of the per-lane stacks in the workgroup's LDS array.  Lane-major (a lane's entries are consecutive
+// words, lanes kStackDepth words apart - an odd number, so lanes at the same level still fall into different
+// banks): moving the top is +-4 bytes, which fits an instruction's inline constant; level-major
+// (stack[level][lane]) needs +-256 and two registers to hold those.
+#ifndef PTK_STACK_LANE_MAJOR
+#define PTK_STACK_LANE_MAJOR 1
+#endif
 struct LdsStack {
-  uint32_t* top;   // this lane's top entry in the workgroup's LDS array (entries of a lane are kBlock words apart)
+  static constexpr int kStep = PTK_STACK_LANE_MAJOR ? 1 : kBlock;  // words between a lane's consecutive entries
+  uint32_t* top;   // this lane's top entry
   uint32_t* base;  // this lane's entry 0
+  __device__ __forceinline__ void attach(uint32_t* array, int lane) { base = top = array + (PTK_STACK_LANE_MAJOR ? lane * kStackDepth : lane); }
   __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
-  __device__ __forceinline__ void push(uint32_t v) { top += kBlock; *top = v; }
-  __device__ __forceinline__ uint32_t pop() { uint32_t v = *top; top -= kBlock; return v; }
+  __device__ __forceinline__ void push(uint32_t v) { top += kStep; *top = v; }
+  __device__ __forceinline__ uint32_t pop() { uint32_t v = *top; top -= kStep; return v; }
   // Branch-free: the entry above the top is scratch, so v is always written there and only counts
   // if the top moves up.  The builder keeps trees shallower than the stack (ptk_upload_scene checks).
   __device__ __forceinline__ uint32_t step(bool do_push, uint32_t v, bool do_pop)
   {
     uint32_t t = *top;
-    top[kBlock] = v;
-    top += (do_push ? kBlock : 0) - (do_pop ? kBlock : 0);
+    top[kStep] = v;
+    // at most one of the two is set; a byte step of +-4 (lane-major) is an inline constant of the select
+    const int step_bytes = do_push ? kStep * 4 : (do_pop ? -kStep * 4 : 0);
+    top = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top) + step_bytes);
     return t;
   }
 };
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
-  st.base = st.top = lds_stack + threadIdx.x;
+  st.attach(lds_stack, (int)threadIdx.x);
 
   // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
   // tile, then the next tile of the same tile row; tile rows are dealt to the XCDs round-robin
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   LdsStack st;
-  st.base = st.top = lds_stack + threadIdx.x;
+  st.attach(lds_stack, (int)threadIdx.x);
   Counters cnt = {0, 0, 0, 0, 0};
   // A wave owns a contiguous run of the batch (the grid is capped by launch_intersect: a quarter of a million
   // one-shot workgroups, each ending in counter atomics, cost ten times the traversal) and works through it
@@ -596,7 +607,7 @@ int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t build
     if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); return rc; }
     DeviceTree tree;
     why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
-                            h.centroid_hi, h.max_diagonal, tree);
+                            h.centroid_hi, h.max_diagonal, h.grid, tree);
     (void)hipFree(d_boxes);
     (void)hipFree(d_by_id);
     if (!why.empty()) return fail(ctx, PTK_ERR_HIP, "ptk_upload_scene: " + why);

@@ -20,16 +20,62 @@ constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
 constexpr int kStackDepth = PTK_STACK_DEPTH;
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 
-// Inner node with the boxes of BOTH children (one 64-byte fetch decides both).
+// Inner node with the boxes of BOTH children, 32 bytes: two 16-byte fetches per lane decide both.  The
+// render kernel is bound by the number of cache accesses a wave makes (every lane is at its own node, so each
+// 16-byte load is one access per lane), which is why the boxes are not stored as floats: box planes are
+// 16-bit positions on a grid over the scene's bounds (BoxGrid), rounded outwards, low plane in the low half
+// of a word and high plane in the high half.
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first_prim << 3) | (count - 1).
-// kEmptyChild marks a child that holds nothing (its box is inverted so it is never entered).
 struct alignas(16) NodePair {
-  f4 xy0;  // child 0: min.x, max.x, min.y, max.y
-  f4 xy1;  // child 1: min.x, max.x, min.y, max.y
-  f4 zz;   // child 0: min.z, max.z; child 1: min.z, max.z
-  int32_t child0, child1, pad0, pad1;
+  uint32_t x0, y0, z0;  // child 0
+  uint32_t x1;          // child 1
+  uint32_t y1, z1;
+  int32_t child0, child1;
 };
-static_assert(sizeof(NodePair) == 64, "NodePair must be one 64-byte line");
+static_assert(sizeof(NodePair) == 32, "NodePair must be two 16-byte fetches");
+
+// plane position = origin + q * scale for q in 0 .. 65535, per axis
+struct BoxGrid {
+  float origin[3], scale[3];
+};
+
+// Grid covering the box [lo, hi] (which has been padded already, so no axis is empty).
+PTK_HD BoxGrid make_box_grid(const float lo[3], const float hi[3])
+{
+  BoxGrid g;
+  for (int a = 0; a < 3; a++) {
+    g.origin[a] = lo[a];
+    g.scale[a] = fmaxf((hi[a] - lo[a]) / 65534.0f, 1e-30f);
+  }
+  return g;
+}
+
+// Largest grid position not above v / smallest not below v, as the traversal evaluates positions
+// (fused multiply-add in fp32), so that a quantised box always contains the box it was made from.
+PTK_HD uint32_t grid_floor(float v, float origin, float scale)
+{
+  float q = fminf(fmaxf(floorf((v - origin) / scale), 0.0f), 65535.0f);
+  while (q > 0.0f && fmaf(q, scale, origin) > v) q -= 1.0f;
+  return (uint32_t)q;
+}
+PTK_HD uint32_t grid_ceil(float v, float origin, float scale)
+{
+  float q = fminf(fmaxf(ceilf((v - origin) / scale), 0.0f), 65535.0f);
+  while (q < 65535.0f && fmaf(q, scale, origin) < v) q += 1.0f;
+  return (uint32_t)q;
+}
+PTK_HD uint32_t grid_word(float lo, float hi, float origin, float scale)
+{
+  return grid_floor(lo, origin, scale) | (grid_ceil(hi, origin, scale) << 16);
+}
+PTK_HD void set_child_box(NodePair& n, int which, const float lo[3], const float hi[3], const BoxGrid& g)
+{
+  uint32_t x = grid_word(lo[0], hi[0], g.origin[0], g.scale[0]);
+  uint32_t y = grid_word(lo[1], hi[1], g.origin[1], g.scale[1]);
+  uint32_t z = grid_word(lo[2], hi[2], g.origin[2], g.scale[2]);
+  if (which == 0) { n.x0 = x; n.y0 = y; n.z0 = z; }
+  else { n.x1 = x; n.y1 = y; n.z1 = z; }
+}
 
 enum PrimKind : uint32_t { kTriangle = 0, kSphere = 1 };
 
@@ -98,6 +144,7 @@ struct SceneView {
   const uint8_t* texels;
   int32_t n_prims, n_lights, n_nodes, n_materials;
   int32_t n_triangles;  // primitive ids 0 .. n_triangles-1 are triangles, the rest spheres (the C ABI's order)
+  BoxGrid grid;         // what the nodes' box planes are positions on
   int32_t background_texture;  // -1 = none
   int32_t background_is_color; // all components >= 0 (src/scene.cpp:39)
   float background_color[3];

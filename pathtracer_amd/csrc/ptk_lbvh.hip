@@ -120,16 +120,24 @@ __global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t
   const int32_t c0 = child(a, n0), c1 = child(mid, n1);
   nodes[i].child0 = c0;
   nodes[i].child1 = c1;
-  nodes[i].pad0 = nodes[i].pad1 = 0;
 }
 
-struct DevBox {
-  float lo[3], hi[3];
+// A box as the nodes store it: per axis, low grid plane | high grid plane << 16.
+struct QBox {
+  uint32_t x, y, z;
 };
 
-__device__ inline float half_area(const DevBox& b)
+__device__ inline uint32_t q_union(uint32_t a, uint32_t b)
 {
-  float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  uint32_t lo = min(a & 0xffffu, b & 0xffffu), hi = max(a >> 16, b >> 16);
+  return lo | (hi << 16);
+}
+
+__device__ inline float q_half_area(const QBox& b, const BoxGrid& g)
+{
+  float dx = (float)((b.x >> 16) - (b.x & 0xffffu)) * g.scale[0];
+  float dy = (float)((b.y >> 16) - (b.y & 0xffffu)) * g.scale[1];
+  float dz = (float)((b.z >> 16) - (b.z & 0xffffu)) * g.scale[2];
   return dx * dy + dy * dz + dz * dx;
 }
 
@@ -138,31 +146,31 @@ constexpr float kTraversalCost = 1.0f, kIntersectCost = 1.2f;  // the host build
 // Box of the child behind `link`.  An inner child whose own children are both leaves, of at most
 // kMaxLeafSize primitives together, is replaced by one leaf when testing all of them costs no more
 // (surface-area heuristic) than visiting the node first; `link` is updated then and the node is left unused.
-__device__ inline DevBox child_box(int32_t& link, const float* __restrict__ boxes, const uint32_t* __restrict__ order,
-                                   const NodePair* nodes)
+__device__ inline QBox child_box(int32_t& link, const float* __restrict__ boxes, const uint32_t* __restrict__ order,
+                                 const NodePair* nodes, const BoxGrid& g)
 {
-  DevBox r;
+  QBox r;
   if (link < 0) {
     const uint32_t leaf = ~(uint32_t)link;
     const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
-    for (int k = 0; k < 3; k++) { r.lo[k] = 3.0e38f; r.hi[k] = -3.0e38f; }
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (uint32_t j = 0; j < count; j++) {
       const float* b = boxes + 6 * (size_t)order[first + j];
-      for (int k = 0; k < 3; k++) { r.lo[k] = fminf(r.lo[k], b[k]); r.hi[k] = fmaxf(r.hi[k], b[3 + k]); }
+      for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); }
     }
+    r.x = grid_word(lo[0], hi[0], g.origin[0], g.scale[0]);
+    r.y = grid_word(lo[1], hi[1], g.origin[1], g.scale[1]);
+    r.z = grid_word(lo[2], hi[2], g.origin[2], g.scale[2]);
   } else {
     const NodePair c = nodes[link];
-    r.lo[0] = fminf(c.xy0.x, c.xy1.x); r.hi[0] = fmaxf(c.xy0.y, c.xy1.y);
-    r.lo[1] = fminf(c.xy0.z, c.xy1.z); r.hi[1] = fmaxf(c.xy0.w, c.xy1.w);
-    r.lo[2] = fminf(c.zz.x, c.zz.z);   r.hi[2] = fmaxf(c.zz.y, c.zz.w);
+    const QBox b0{c.x0, c.y0, c.z0}, b1{c.x1, c.y1, c.z1};
+    r.x = q_union(b0.x, b1.x); r.y = q_union(b0.y, b1.y); r.z = q_union(b0.z, b1.z);
     if (c.child0 < 0 && c.child1 < 0) {
       const uint32_t l0 = ~(uint32_t)c.child0, l1 = ~(uint32_t)c.child1;
       const uint32_t n0 = (l0 & 7u) + 1u, n1 = (l1 & 7u) + 1u;
       if (n0 + n1 <= (uint32_t)kMaxLeafSize) {  // the two ranges are adjacent: l1 starts where l0 ends
-        const DevBox b0{{c.xy0.x, c.xy0.z, c.zz.x}, {c.xy0.y, c.xy0.w, c.zz.y}};
-        const DevBox b1{{c.xy1.x, c.xy1.z, c.zz.z}, {c.xy1.y, c.xy1.w, c.zz.w}};
-        const float a = half_area(r);
-        const float split = kTraversalCost * a + kIntersectCost * (half_area(b0) * (float)n0 + half_area(b1) * (float)n1);
+        const float a = q_half_area(r, g);
+        const float split = kTraversalCost * a + kIntersectCost * (q_half_area(b0, g) * (float)n0 + q_half_area(b1, g) * (float)n1);
         const float leaf = kIntersectCost * a * (float)(n0 + n1);
         if (leaf <= split) link = leaf_link(l0 >> 3, n0 + n1);
       }
@@ -175,21 +183,20 @@ __device__ inline DevBox child_box(int32_t& link, const float* __restrict__ boxe
 __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __restrict__ boxes,
                                                                 const uint32_t* __restrict__ order, NodePair* nodes,
                                                                 uint32_t begin, uint32_t end, uint32_t* __restrict__ live,
-                                                                uint32_t* __restrict__ subtree)
+                                                                uint32_t* __restrict__ subtree, BoxGrid g)
 {
   uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= end) return;
   int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
-  const DevBox b0 = child_box(c0, boxes, order, nodes), b1 = child_box(c1, boxes, order, nodes);
+  const QBox b0 = child_box(c0, boxes, order, nodes, g), b1 = child_box(c1, boxes, order, nodes, g);
   nodes[i].child0 = c0;
   nodes[i].child1 = c1;
   // A node merged into a leaf has only leaves below it, so whatever an inner link still points at is in use.
   if (c0 >= 0) live[c0] = 1u;
   if (c1 >= 0) live[c1] = 1u;
   subtree[i] = 1u + (c0 >= 0 ? subtree[c0] : 0u) + (c1 >= 0 ? subtree[c1] : 0u);  // inner nodes in use from here down
-  nodes[i].xy0 = f4{b0.lo[0], b0.hi[0], b0.lo[1], b0.hi[1]};
-  nodes[i].xy1 = f4{b1.lo[0], b1.hi[0], b1.lo[1], b1.hi[1]};
-  nodes[i].zz = f4{b0.lo[2], b0.hi[2], b1.lo[2], b1.hi[2]};
+  nodes[i].x0 = b0.x; nodes[i].y0 = b0.y; nodes[i].z0 = b0.z;
+  nodes[i].x1 = b1.x; nodes[i].y1 = b1.y; nodes[i].z1 = b1.z;
 }
 
 // Final positions, top-down: depth-first order (a node, its first child's whole subtree, then the second
@@ -252,7 +259,7 @@ inline unsigned blocks_for(uint32_t n) { return (n + kBuildBlock - 1) / kBuildBl
 
 std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n,
                               const float centroid_lo[3], const float centroid_hi[3], float max_diagonal,
-                              DeviceTree& out)
+                              const BoxGrid& grid, DeviceTree& out)
 {
   out = DeviceTree();
   if (n < 2 * kMaxLeafSize) return "device tree build needs at least " + std::to_string(2 * kMaxLeafSize) + " primitives";
@@ -326,7 +333,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   LBVH_HIP(hipMemsetAsync(new_index, 0, sizeof(uint32_t), stream));                 // stays node 0
   for (size_t l = levels.size(); l-- > 0;) {
     fit_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
-        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree);
+        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree, grid);
     LBVH_HIP(hipGetLastError());
   }
   for (size_t l = 0; l < levels.size(); l++) {

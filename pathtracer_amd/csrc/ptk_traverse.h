@@ -83,23 +83,34 @@ PTK_HD bool hit_sphere(const PrimRec& p, v3 o, v3 d, float tbest, bool own_surfa
   return true;
 }
 
-// Slab test of one child box against [0, tbest]; returns entry distance in tn.
-// fminf/fmaxf drop NaNs from 0 * inf, so an axis-parallel ray lying exactly in a box face
-// is kept on that axis (the reference's comparisons do the same, src/aabb.cpp:54-62).
-// Plane distances are formed as fma(plane, 1/d, -(o/d)): one instruction per plane.  The caller keeps 1/d
-// finite (axis-parallel rays get +-1e20), so a slab the origin lies in gives -huge..+huge and a slab it lies
-// outside gives two huge values of one sign.  The rounding of o/d is covered by the padding the builder puts
-// on every box.
-PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float hiz, v3 oi, v3 inv, float tbest,
-                    float& tn)
+// min of two numbers that are known not to be NaN.  fminf would first quiet a possible signalling NaN
+// in an operand it knows nothing about (one more instruction per call; tbest is such an operand).
+PTK_HD float min_raw(float a, float b)
 {
-  float tx0 = fmaf(lox, inv.x, -oi.x), tx1 = fmaf(hix, inv.x, -oi.x);
-  float ty0 = fmaf(loy, inv.y, -oi.y), ty1 = fmaf(hiy, inv.y, -oi.y);
-  float tz0 = fmaf(loz, inv.z, -oi.z), tz1 = fmaf(hiz, inv.z, -oi.z);
+#if defined(__HIP_DEVICE_COMPILE__)
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a < b ? a : b;
+#endif
+}
+
+// Slab test of one child box against [0, tbest]; returns entry distance in tn.  wx, wy, wz: the box's grid
+// words (low plane | high plane << 16).  The ray carries inv = grid scale / d and oi = (o - grid origin) / d
+// per axis, so the distance to grid plane q is fma(q, inv, -oi): one conversion and one fma per plane.
+// fminf/fmaxf drop NaNs, and the caller keeps 1/d finite (axis-parallel rays get +-1e20), so a slab the
+// origin lies in gives -huge..+huge and a slab it lies outside gives two huge values of one sign.  The
+// rounding of these products is covered by the padding the builder puts on every box.
+PTK_HD bool hit_box(uint32_t wx, uint32_t wy, uint32_t wz, v3 oi, v3 inv, float tbest, float& tn)
+{
+  float tx0 = fmaf((float)(wx & 0xffffu), inv.x, -oi.x), tx1 = fmaf((float)(wx >> 16), inv.x, -oi.x);
+  float ty0 = fmaf((float)(wy & 0xffffu), inv.y, -oi.y), ty1 = fmaf((float)(wy >> 16), inv.y, -oi.y);
+  float tz0 = fmaf((float)(wz & 0xffffu), inv.z, -oi.z), tz1 = fmaf((float)(wz >> 16), inv.z, -oi.z);
   float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-  float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+  float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), min_raw(fmaxf(tz0, tz1), tbest));
   tn = tnear;
-  return tnear <= tfar * 1.0000005f;  // a few ulps of slack: boxes of axis-aligned walls have zero thickness
+  return tnear <= tfar;  // no slack needed: the builder pads every box well beyond the rounding of these products
 }
 
 // ---------------------------------------------------------------------------------
@@ -115,7 +126,7 @@ PTK_HD bool hit_box(float lox, float hix, float loy, float hiy, float loz, float
 constexpr int32_t kTravDone = (int32_t)0x80000000;  // not a valid leaf code for < 2^28 primitives
 
 struct Traversal {
-  v3 o, d, inv, oi;  // oi = o * inv (origin in plane-distance units)
+  v3 o, d, inv, oi;  // inv = grid scale / d, oi = (o - grid origin) / d: see hit_box
   Hit hit;
   int32_t node;      // >= 0 inner node, kTravDone finished, other negative values: leaf
   uint32_t skip_id;  // primitive the ray starts on (kNoPrim for none)
@@ -140,9 +151,10 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   // 1/d is kept finite: with an infinite 1/d the fused form below would turn "inf - inf" into NaN for one
   // plane of a slab that contains the origin.  1e20 keeps every product far inside the float range.
   const float big = 1e20f;
-  tr.inv = V3(fmaxf(fminf(frcp(d.x), big), -big), fmaxf(fminf(frcp(d.y), big), -big),
-              fmaxf(fminf(frcp(d.z), big), -big));
-  tr.oi = o * tr.inv;
+  const v3 rd = V3(fmaxf(fminf(frcp(d.x), big), -big), fmaxf(fminf(frcp(d.y), big), -big),
+                   fmaxf(fminf(frcp(d.z), big), -big));
+  tr.inv = V3(rd.x * sc.grid.scale[0], rd.y * sc.grid.scale[1], rd.z * sc.grid.scale[2]);
+  tr.oi = V3((o.x - sc.grid.origin[0]) * rd.x, (o.y - sc.grid.origin[1]) * rd.y, (o.z - sc.grid.origin[2]) * rd.z);
   tr.hit.t = tmax;
   tr.hit.id = kNoPrim;
   tr.hit.u = tr.hit.v = 0.0f;
@@ -162,11 +174,13 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   const NodePair n = *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) +
                                                          ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)));
   float tn0, tn1;
-  bool h0 = hit_box(n.xy0.x, n.xy0.y, n.xy0.z, n.xy0.w, n.zz.x, n.zz.y, tr.oi, tr.inv, tr.hit.t, tn0);
-  bool h1 = hit_box(n.xy1.x, n.xy1.y, n.xy1.z, n.xy1.w, n.zz.z, n.zz.w, tr.oi, tr.inv, tr.hit.t, tn1);
+  bool h0 = hit_box(n.x0, n.y0, n.z0, tr.oi, tr.inv, tr.hit.t, tn0);
+  bool h1 = hit_box(n.x1, n.y1, n.z1, tr.oi, tr.inv, tr.hit.t, tn1);
   if (STATS) cnt.box_tests += 2;
-  const bool both = h0 & h1, none = !(h0 | h1);
-  const bool first1 = h1 & (!h0 | (tn1 < tn0));  // child 1 is the one to visit first
+  // logical operators on purpose: the results stay lane masks (scalar and/or) instead of 0/1 integers
+  const bool both = h0 && h1, none = !h0 && !h1;
+  const bool closer1 = tn1 < tn0;
+  const bool first1 = h1 && (!h0 || closer1);  // child 1 is the one to visit first
   const int32_t near = first1 ? n.child1 : n.child0, far = first1 ? n.child0 : n.child1;
   const uint32_t top = st.step(both, (uint32_t)far, none);
   tr.node = none ? (int32_t)top : near;

@@ -199,7 +199,7 @@ def test_tree_cache_round_trip(tmp_path, monkeypatch):
     # corrupt one child link in the middle of the node array: the file must be refused, the tree rebuilt
     raw = bytearray(files[0].read_bytes())
     header = 8 + 16 + 16
-    link = header + 64 * 10 + 48
+    link = header + 32 * 10 + 24  # child0 of node 10
     raw[link:link + 4] = (0x7fffff00).to_bytes(4, "little")
     files[0].write_bytes(bytes(raw))
     third = HostBackend(sd)

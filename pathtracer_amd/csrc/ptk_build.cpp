@@ -54,7 +54,10 @@ int median_levels(int n)
 
 constexpr int kBins = 16;
 constexpr float kTraversalCost = 1.0f;
-constexpr float kIntersectCost = 1.2f;
+#ifndef PTK_SAH_INTERSECT_COST
+#define PTK_SAH_INTERSECT_COST 1.2f
+#endif
+constexpr float kIntersectCost = PTK_SAH_INTERSECT_COST;
 
 // Binned surface-area-heuristic builder.  Subtrees are independent, so the two sides of a large
 // split are built by different threads; which thread builds what does not influence the tree (every

@@ -437,6 +437,9 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
                        Counters& cnt)
 {
   const v3 o = ps.tr.o, d = ps.tr.d;
+#ifdef PTK_BURN_SHADE
+  for (int burn = 0; burn < PTK_BURN_SHADE; burn++) PTK_BURN12(ps.tr.node);
+#endif
   if (ps.tr.hit.id == kNoPrim) {
     ps.L += ps.beta * background(sc, d);  // src/renderer.cpp:67-69
     return true;

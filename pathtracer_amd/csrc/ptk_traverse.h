@@ -163,6 +163,17 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   tr.node = sc.n_prims > 0 ? 0 : kTravDone;
 }
 
+// Experiment hook (-DPTK_BURN_*): twelve extra vector instructions, to weigh a code region's share of the
+// kernel's time by how much slower it gets.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTK_BURN12(x)                                                                                              \
+  asm volatile("v_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\n" \
+               "v_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0\nv_mov_b32 %0, %0"    \
+               : "+v"(x))
+#else
+#define PTK_BURN12(x) (void)(x)
+#endif
+
 // Visit one inner node.  Straight-line code: whether a child is pushed, and whether the next node
 // comes from the stack, are decided by selects, and the stack is touched the same way every time
 // (Stack::step reads the top entry, writes the candidate above it and then moves the stack pointer).
@@ -173,6 +184,17 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   // (loaded whole, by value: the child links must not become a second, dependent fetch)
   const NodePair n = *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) +
                                                          ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)));
+#ifdef PTK_EXTRA_LOAD  // experiment: one more cache access per node visit, result unused
+  {
+    const volatile int32_t* extra = reinterpret_cast<const volatile int32_t*>(reinterpret_cast<const char*>(sc.nodes) +
+                                                                             ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)) + 28);
+    int32_t x = *extra;
+    asm volatile("" ::"v"(x));
+  }
+#endif
+#ifdef PTK_BURN_INNER
+  for (int burn = 0; burn < PTK_BURN_INNER; burn++) PTK_BURN12(tr.node);
+#endif
   float tn0, tn1;
   bool h0 = hit_box(n.x0, n.y0, n.z0, tr.oi, tr.inv, tr.hit.t, tn0);
   bool h1 = hit_box(n.x1, n.y1, n.z1, tr.oi, tr.inv, tr.hit.t, tn1);
@@ -192,6 +214,9 @@ PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
 {
   const uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
   if (STATS) cnt.prim_tests++;
+#ifdef PTK_BURN_PRIM
+  for (int burn = 0; burn < PTK_BURN_PRIM; burn++) PTK_BURN12(tr.node);
+#endif
   float t = 0.0f, u = 0.0f, v = 0.0f;
   bool ok;
   if (kind == kTriangle) {

@@ -194,7 +194,7 @@ def main():
                          "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray, "l2_hit_rate": l2_hit,
                          "note": "achieved counts every box and primitive test as bytes fetched; the scene is "
                                  "cache resident (traffic << algorithmic bytes), so frac can exceed 1; the "
-                                 "kernel is bound by L1 accesses per ray and VALU issue: see fp32_valu and profiles/",
+                                 "kernel is bound by load latency and L1 accesses per ray, not by HBM: see fp32_valu and profiles/",
                          "kernel": "render_kernel", "kernel_ms_avg": kernel_s * 1e3,
                          "bytes_per_ray": bytes_per_ray, "box_tests_per_ray": box_per_ray,
                          "prim_tests_per_ray": prim_per_ray, "rays_per_launch": rays_per_launch,

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       const bool want = trav_at_inner(ps.tr);
       const int n_want = __popcll(__ballot(want));
       // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no leaf is held
-      if (n_want == 0 || (n_want < kDescendMin && __ballot(held != kTravDone) != 0ull)) break;
+      const bool any_held = __ballot(held != kTravDone) != 0ull;
+      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
       if (trav_at_leaf(tr) && held == kTravDone) { held = tr.node; tr.node = (int32_t)st.pop(); }
       const bool want = trav_at_inner(tr);
       const int n_want = __popcll(__ballot(want));
-      if (n_want == 0 || (n_want < kDescendMin && __ballot(held != kTravDone) != 0ull)) break;
+      const bool any_held = __ballot(held != kTravDone) != 0ull;
+      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
       if (want) trav_inner<LdsStack, STATS>(tr, st, sc, cnt);
     }
     if (held != kTravDone) {

@@ -195,6 +195,16 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
 #ifdef PTK_BURN_INNER
   for (int burn = 0; burn < PTK_BURN_INNER; burn++) PTK_BURN12(tr.node);
 #endif
+#ifdef PTK_BURN_INNER_FMA  // same with dependent fused multiply-adds on a scratch value
+  {
+    float scratch = tr.hit.t;
+    for (int burn = 0; burn < PTK_BURN_INNER_FMA; burn++)
+      asm volatile("v_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\n"
+                   "v_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\n"
+                   "v_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0\nv_fma_f32 %0, %0, %0, %0"
+                   : "+v"(scratch));
+  }
+#endif
   float tn0, tn1;
   bool h0 = hit_box(n.x0, n.y0, n.z0, tr.oi, tr.inv, tr.hit.t, tn0);
   bool h1 = hit_box(n.x1, n.y1, n.z1, tr.oi, tr.inv, tr.hit.t, tn1);

@@ -605,8 +605,8 @@ int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t build
   int rc;
   if (on_device) {
     void *d_boxes = nullptr, *d_by_id = nullptr;
-    if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) return rc;
-    if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); return rc; }
+    if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) { if (d_boxes) (void)hipFree(d_boxes); return rc; }
+    if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); if (d_by_id) (void)hipFree(d_by_id); return rc; }
     DeviceTree tree;
     why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
                             h.centroid_hi, h.max_diagonal, h.grid, tree);

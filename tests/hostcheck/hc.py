@@ -39,6 +39,7 @@ def lib():
         L.hc_error.restype = C.c_char_p
         L.hc_destroy.argtypes = [vp]
         L.hc_info.argtypes = [vp, vp]
+        L.hc_tree_check.argtypes = [vp, vp]
         L.hc_intersect.argtypes = [vp, vp, C.c_int, vp, vp]
         L.hc_render.argtypes = [vp, C.POINTER(native.PtkCamera), C.POINTER(native.PtkFlags),
                                 C.POINTER(native.PtkRenderParams), vp, vp]
@@ -68,6 +69,11 @@ class HostCheck:
         lib().hc_info(self.h, out.ctypes.data)
         return dict(n_nodes=int(out[0]), max_depth=int(out[1]), max_leaf=int(out[2]), n_lights=int(out[3]),
                     n_prims=int(out[4]), tree_from_cache=int(out[5]))
+
+    def tree_check(self):
+        out = np.zeros(3, np.int64)
+        lib().hc_tree_check(self.h, out.ctypes.data)
+        return dict(violations=int(out[0]), reached=int(out[1]), deepest=int(out[2]))
 
     def intersect(self, rays):
         rays = np.asarray(rays, np.float64).reshape(-1, 6)

@@ -60,6 +60,69 @@ void hc_info(void* h, int32_t* out /* n_nodes, max_depth, max_leaf, n_lights, n_
   out[5] = c->host.tree_from_cache ? 1 : 0;
 }
 
+// Walks the flattened tree and checks, in double precision, that every child's grid box contains all the
+// primitives below it and that every primitive is below exactly one leaf.
+// out: violations (a primitive sticking out of a box on its path), primitives reached, deepest leaf level.
+void hc_tree_check(void* h, int64_t* out)
+{
+  Check* c = (Check*)h;
+  const HostScene& hs = c->host;
+  const BoxGrid g = hs.grid;
+  struct Todo { int32_t link; int depth; double lo[3], hi[3]; };
+  std::vector<Todo> stack;
+  int64_t violations = 0, reached = 0, deepest = 0;
+  auto decode = [&](uint32_t wx, uint32_t wy, uint32_t wz, Todo& t) {
+    const uint32_t w[3] = {wx, wy, wz};
+    for (int a = 0; a < 3; a++) {
+      t.lo[a] = (double)g.origin[a] + (double)(w[a] & 0xffffu) * (double)g.scale[a];
+      t.hi[a] = (double)g.origin[a] + (double)(w[a] >> 16) * (double)g.scale[a];
+    }
+  };
+  const NodePair& root = hs.nodes[0];
+  Todo a, b;
+  a.link = root.child0; a.depth = 1; decode(root.x0, root.y0, root.z0, a);
+  b.link = root.child1; b.depth = 1; decode(root.x1, root.y1, root.z1, b);
+  stack.push_back(a);
+  if (!(root.child1 == root.child0 && root.child0 < 0)) stack.push_back(b);  // a one-leaf scene repeats its leaf
+  while (!stack.empty()) {
+    Todo t = stack.back(); stack.pop_back();
+    if (t.depth > deepest) deepest = t.depth;
+    if (t.link >= 0) {
+      const NodePair& n = hs.nodes[t.link];
+      Todo c0, c1;
+      c0.link = n.child0; c0.depth = t.depth + 1; decode(n.x0, n.y0, n.z0, c0);
+      c1.link = n.child1; c1.depth = t.depth + 1; decode(n.x1, n.y1, n.z1, c1);
+      // boxes are rounded independently, so a child's box may stick out of its parent's by a grid step; what
+      // the traversal relies on is that EVERY box on the path contains the primitive: carry their intersection
+      for (int k = 0; k < 3; k++) {
+        c0.lo[k] = std::max(c0.lo[k], t.lo[k]); c0.hi[k] = std::min(c0.hi[k], t.hi[k]);
+        c1.lo[k] = std::max(c1.lo[k], t.lo[k]); c1.hi[k] = std::min(c1.hi[k], t.hi[k]);
+      }
+      stack.push_back(c0); stack.push_back(c1);
+      continue;
+    }
+    const uint32_t leaf = ~(uint32_t)t.link, first = leaf >> 3, count = (leaf & 7u) + 1u;
+    for (uint32_t i = first; i < first + count && i < hs.prims.size(); i++) {
+      const PrimRec& p = hs.prims[i];
+      double lo[3], hi[3];
+      if (as_uint(p.c.z) == kTriangle) {
+        const double v0[3] = {p.a.x, p.a.y, p.a.z}, e1[3] = {p.a.w, p.b.x, p.b.y}, e2[3] = {p.b.z, p.b.w, p.c.x};
+        for (int k = 0; k < 3; k++) {
+          lo[k] = std::min(v0[k], std::min(v0[k] + e1[k], v0[k] + e2[k]));
+          hi[k] = std::max(v0[k], std::max(v0[k] + e1[k], v0[k] + e2[k]));
+        }
+      } else {
+        const double ctr[3] = {p.a.x, p.a.y, p.a.z};
+        for (int k = 0; k < 3; k++) { lo[k] = ctr[k] - std::fabs((double)p.a.w); hi[k] = ctr[k] + std::fabs((double)p.a.w); }
+      }
+      reached++;
+      for (int k = 0; k < 3; k++)
+        if (lo[k] < t.lo[k] || hi[k] > t.hi[k]) { violations++; break; }
+    }
+  }
+  out[0] = violations; out[1] = reached; out[2] = deepest;
+}
+
 // returns the deepest stack use seen
 int hc_intersect(void* h, const ptk_ray* rays, int n, ptk_hit* hits, uint64_t* counters /* box, prim */)
 {

@@ -214,3 +214,17 @@ def test_tree_cache_round_trip(tmp_path, monkeypatch):
     assert HostBackend(other).info()["tree_from_cache"] == 0
     assert len(list(tmp_path.glob("ptkbvh-*.bin"))) == 2
     assert not list(tmp_path.glob("*.tmp*"))
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "mesh", "glass", "sky"])
+def test_grid_boxes_contain_their_primitives(scene_name):
+    """Node boxes are stored as 16-bit grid positions rounded outwards: every primitive must lie inside the
+    intersection of all boxes on its path (checked in double precision), be reached exactly once, and no leaf
+    may lie deeper than the traversal stack allows."""
+    from tests.backends import HostBackend, scene
+    b = HostBackend(scene(scene_name))
+    r = b.k.tree_check()
+    info = b.info()
+    assert r["violations"] == 0, r
+    assert r["reached"] == info["n_prims"], (r, info)
+    assert r["deepest"] == info["max_depth"] <= 25, (r, info)

@@ -94,3 +94,23 @@ def test_equal_keys_and_tiny_scenes(gpu_ctx):
     small = scene("cornell_pinhole")
     b = GpuBackend(gpu_ctx, small, builder="device")
     assert b.info()["builder"] == 0 and b.info()["device_build_ms"] == 0.0
+
+
+def test_device_tree_on_a_scaled_and_offset_scene(gpu_ctx):
+    """Sort keys and grid boxes are relative to the scene's bounds: a scene far from the origin and 100x larger
+    must still give the oracle's hits."""
+    import copy
+    sd = copy.deepcopy(scene("mesh"))
+    off = np.array([500.0, -300.0, 200.0])
+    sd.tri_pos = sd.tri_pos * 100.0 + off
+    sd.sphere_center = sd.sphere_center * 100.0 + off
+    sd.sphere_radius = sd.sphere_radius * 100.0
+    rays = np.concatenate([raygen.interior_rays(20000, 42), raygen.camera_like_rays(10000, 43)])
+    rays[:, :3] = rays[:, :3] * 100.0 + off
+    rays = _f32_rays(rays)
+    ref, _ = orc.OracleScene(sd).intersect(rays)
+    b = GpuBackend(gpu_ctx, sd, builder="device")
+    assert b.info()["builder"] == 1
+    got, _ = b.intersect(rays)
+    c = parity.classify_hits(sd, rays, ref, got)
+    assert c["unexplained"] == 0 and c["ok"] >= c["n"] - 3, c

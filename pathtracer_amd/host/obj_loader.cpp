@@ -2,12 +2,14 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 
 namespace pt {
 
@@ -79,8 +81,13 @@ struct Cursor {
   }
 };
 
-// "7", "7/3", "7//2", "7/3/2" in [b, e); negative values count back from the end
-bool parse_index_range(const char* b, const char* e, int nv, int nvt, int nvn, Index& out)
+// One vertex reference of a face as written: "7", "7/3", "7//2", "7/3/2" in [b, e).  Values keep their
+// sign (negative = relative to the elements read so far); 0 = absent.
+struct RawIndex {
+  int v = 0, vt = 0, vn = 0;
+};
+
+bool parse_raw_index(const char* b, const char* e, RawIndex& out)
 {
   int vals[3] = {0, 0, 0};
   bool have[3] = {false, false, false};
@@ -98,19 +105,181 @@ bool parse_index_range(const char* b, const char* e, int nv, int nvt, int nvn, I
     if (q < e && *q == '/') { q++; k++; continue; }
     break;
   }
-  if (q != e || !have[0]) return false;
-  auto fix = [](int i, int n) { return i > 0 ? i : (i < 0 ? n + i + 1 : 0); };
-  out.v = fix(vals[0], nv);
-  out.vt = have[1] ? fix(vals[1], nvt) : 0;
-  out.vn = have[2] ? fix(vals[2], nvn) : 0;
-  return out.v >= 1 && out.v <= nv && out.vt >= 0 && out.vt <= nvt && out.vn >= 0 && out.vn <= nvn;
+  if (q != e || !have[0] || vals[0] == 0) return false;
+  out.v = vals[0];
+  out.vt = have[1] ? vals[1] : 0;
+  out.vn = have[2] ? vals[2] : 0;
+  return true;
+}
+
+// A contiguous piece of the file (whole lines) and what one thread read out of it.
+struct Chunk {
+  const char* begin = nullptr;
+  const char* end = nullptr;
+  std::vector<float> v, vt, vn;
+  struct Face {
+    uint32_t first;       // into `refs`
+    uint32_t count;       // vertex references
+    uint32_t nv, nvt, nvn;  // elements of this chunk read before the face (for relative indices)
+    uint32_t line;        // line within the chunk, from 1
+    int32_t event;        // index of the last usemtl of this chunk before the face, -1 = none yet
+  };
+  std::vector<Face> faces;
+  std::vector<RawIndex> refs;
+  struct Event {  // usemtl / mtllib lines, resolved in file order after all chunks are read
+    bool is_lib;
+    std::vector<std::string> names;
+    int material = -1;  // usemtl: resolved id
+  };
+  std::vector<Event> events;
+  size_t lines = 0;
+  size_t error_line = 0;  // first unparsable face line (within the chunk), 0 = none
+  size_t triangles = 0;
+  // filled between the passes
+  size_t v_before = 0, vt_before = 0, vn_before = 0, lines_before = 0, tri_before = 0;
+  int material_at_start = -1;
+  std::string warning;
+  size_t range_error_line = 0;
+};
+
+void read_chunk(Chunk& c)
+{
+  const size_t bytes = (size_t)(c.end - c.begin);
+  c.v.reserve(bytes / 40);
+  c.refs.reserve(bytes / 24);
+  c.faces.reserve(bytes / 72);
+  const char* p = c.begin;
+  int32_t last_event = -1;
+  while (p < c.end) {
+    const char* nl = (const char*)std::memchr(p, '\n', (size_t)(c.end - p));
+    Cursor cur{p, nl ? nl : c.end};
+    p = nl ? nl + 1 : c.end;
+    c.lines++;
+    const char *kb, *ke;
+    if (!cur.token(kb, ke) || *kb == '#') continue;
+    const size_t klen = (size_t)(ke - kb);
+    auto key_is = [&](const char* k) { return std::strlen(k) == klen && std::memcmp(kb, k, klen) == 0; };
+    if (key_is("v")) {
+      float x = cur.real(), y = cur.real(), z = cur.real();
+      c.v.insert(c.v.end(), {x, y, z});
+    } else if (key_is("vt")) {
+      float a = cur.real(), b = cur.real();
+      c.vt.insert(c.vt.end(), {a, b});
+    } else if (key_is("vn")) {
+      float x = cur.real(), y = cur.real(), z = cur.real();
+      c.vn.insert(c.vn.end(), {x, y, z});
+    } else if (key_is("mtllib") || key_is("usemtl")) {
+      Chunk::Event ev;
+      ev.is_lib = key_is("mtllib");
+      const char *b, *e;
+      while (cur.token(b, e)) { ev.names.emplace_back(b, e); if (!ev.is_lib) break; }
+      if (!ev.is_lib && ev.names.empty()) ev.names.emplace_back();
+      c.events.push_back(std::move(ev));
+      if (!c.events.back().is_lib) last_event = (int32_t)c.events.size() - 1;
+    } else if (key_is("f")) {
+      Chunk::Face f;
+      f.first = (uint32_t)c.refs.size();
+      f.nv = (uint32_t)(c.v.size() / 3); f.nvt = (uint32_t)(c.vt.size() / 2); f.nvn = (uint32_t)(c.vn.size() / 3);
+      f.line = (uint32_t)c.lines;
+      f.event = last_event;
+      const char *b, *e;
+      bool ok = true;
+      while (cur.token(b, e)) {
+        RawIndex r;
+        if (!parse_raw_index(b, e, r)) { ok = false; break; }
+        c.refs.push_back(r);
+      }
+      if (!ok) { if (!c.error_line) c.error_line = c.lines; c.refs.resize(f.first); continue; }
+      f.count = (uint32_t)c.refs.size() - f.first;
+      c.triangles += f.count >= 3 ? f.count - 2 : 0;
+      c.faces.push_back(f);
+    }
+  }
+}
+
+// Second pass over a chunk: with all positions known, resolve the references and write the triangles.
+void emit_chunk(Chunk& c, const std::vector<float>& v, const std::vector<float>& vt, const std::vector<float>& vn, ObjMesh& out)
+{
+  size_t tri = c.tri_before;
+  for (const Chunk::Face& f : c.faces) {
+    if (c.range_error_line) return;
+    if (f.count < 3) { c.warning += "Degenerated face found\n."; continue; }
+    const int nv = (int)(c.v_before + f.nv), nvt = (int)(c.vt_before + f.nvt), nvn = (int)(c.vn_before + f.nvn);
+    auto fix = [](int i, int n) { return i > 0 ? i : (i < 0 ? n + i + 1 : 0); };
+    const RawIndex* raw = &c.refs[f.first];
+    // resolved in place into a small buffer (faces are short; large polygons take the heap once)
+    Index small[8];
+    std::vector<Index> big;
+    Index* idx = small;
+    if (f.count > 8) { big.resize(f.count); idx = big.data(); }
+    bool ok = true;
+    for (uint32_t k = 0; k < f.count; k++) {
+      idx[k].v = fix(raw[k].v, nv);
+      idx[k].vt = fix(raw[k].vt, nvt);
+      idx[k].vn = fix(raw[k].vn, nvn);
+      ok = ok && idx[k].v >= 1 && idx[k].v <= nv && idx[k].vt >= 0 && idx[k].vt <= nvt && idx[k].vn >= 0 && idx[k].vn <= nvn;
+    }
+    if (!ok) { c.range_error_line = f.line; return; }
+    const int material = f.event >= 0 ? c.events[(size_t)f.event].material : c.material_at_start;
+    auto emit = [&](int a, int b2, int c2) {
+      const int t[3] = {a, b2, c2};
+      for (int k = 0; k < 3; k++) {
+        const Index& ix = idx[t[k]];
+        ObjVertex ov;
+        for (int ax = 0; ax < 3; ax++) ov.pos[ax] = v[3 * (size_t)(ix.v - 1) + ax];
+        if (ix.vt > 0) { ov.uv[0] = vt[2 * (size_t)(ix.vt - 1)]; ov.uv[1] = vt[2 * (size_t)(ix.vt - 1) + 1]; ov.has_uv = true; }
+        if (ix.vn > 0) { for (int ax = 0; ax < 3; ax++) ov.normal[ax] = vn[3 * (size_t)(ix.vn - 1) + ax]; ov.has_normal = true; }
+        out.vertices[3 * tri + (size_t)k] = ov;
+      }
+      out.material_ids[tri] = material;
+      tri++;
+    };
+    if (f.count == 3) {
+      emit(0, 1, 2);
+    } else if (f.count == 4) {
+      // split along the shorter diagonal; on a tie take [0,1,3],[1,2,3] (float arithmetic, as tinyobj)
+      const float* p0 = &v[3 * (size_t)(idx[0].v - 1)];
+      const float* p1 = &v[3 * (size_t)(idx[1].v - 1)];
+      const float* p2 = &v[3 * (size_t)(idx[2].v - 1)];
+      const float* p3 = &v[3 * (size_t)(idx[3].v - 1)];
+      float e02x = p2[0] - p0[0], e02y = p2[1] - p0[1], e02z = p2[2] - p0[2];
+      float e13x = p3[0] - p1[0], e13y = p3[1] - p1[1], e13z = p3[2] - p1[2];
+      float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
+      float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
+      if (sqr02 < sqr13) { emit(0, 1, 2); emit(0, 2, 3); }
+      else { emit(0, 1, 3); emit(1, 2, 3); }
+    } else {
+      for (uint32_t k = 1; k + 1 < f.count; k++) emit(0, (int)k, (int)k + 1);
+    }
+  }
+}
+
+template <class F>
+void run_on_threads(size_t n, F&& f)
+{
+  std::vector<std::thread> workers;
+  for (size_t i = 1; i < n; i++) workers.emplace_back([&f, i] { f(i); });
+  f(0);
+  for (auto& w : workers) w.join();
 }
 
 }  // namespace
 
+// Large files are cut into one piece per thread at line ends.  Pass 1 (parallel) parses every piece on its
+// own; then the pieces' element counts give each piece its global offsets, and the mtllib / usemtl lines are
+// replayed in file order (so a usemtl sees exactly the materials loaded before it); pass 2 (parallel) resolves
+// the face references and writes the triangles to their final places.
 bool load_obj_file(const std::filesystem::path& filename, const std::filesystem::path& mtl_search_path, ObjMesh& out,
                    std::string& error)
 {
+  const bool timing = std::getenv("PT_TIMING") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pt obj] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  };
   std::string text;
   {
     FILE* f = std::fopen(filename.string().c_str(), "rb");
@@ -123,89 +292,76 @@ bool load_obj_file(const std::filesystem::path& filename, const std::filesystem:
     std::fclose(f);
     text.resize(got);
   }
-  std::vector<float> v, vt, vn;
-  v.reserve(text.size() / 40);
-  out.vertices.reserve(text.size() / 12);
-  out.material_ids.reserve(text.size() / 36);
+  lap("read");
+  size_t n_chunks = 1;
+  if (text.size() >= (size_t)4 << 20) {
+    n_chunks = std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency()));  // 16 = one GPU's share of a node's cores
+    if (const char* e = std::getenv("PT_LOAD_THREADS")) n_chunks = (size_t)std::max(1, std::atoi(e));
+  }
+  std::vector<Chunk> chunks(n_chunks);
+  {
+    const char* p = text.data();
+    const char* file_end = p + text.size();
+    for (size_t i = 0; i < n_chunks; i++) {
+      chunks[i].begin = p;
+      const char* want = text.data() + text.size() * (i + 1) / n_chunks;
+      if (i + 1 == n_chunks || want >= file_end) p = file_end;
+      else {
+        if (want < p) want = p;
+        const char* nl = (const char*)std::memchr(want, '\n', (size_t)(file_end - want));
+        p = nl ? nl + 1 : file_end;
+      }
+      chunks[i].end = p;
+    }
+  }
+  run_on_threads(n_chunks, [&](size_t i) { read_chunk(chunks[i]); });
+
+  lap("pass 1");
+  // offsets, the first syntax error, materials in file order
+  size_t nv = 0, nvt = 0, nvn = 0, lines = 0, tris = 0;
+  for (Chunk& c : chunks) {
+    c.v_before = nv / 3; c.vt_before = nvt / 2; c.vn_before = nvn / 3; c.lines_before = lines; c.tri_before = tris;
+    nv += c.v.size(); nvt += c.vt.size(); nvn += c.vn.size(); lines += c.lines; tris += c.triangles;
+  }
   std::map<std::string, int> mat_by_name;
   int current_material = -1;
-  size_t line_no = 0;
-  std::vector<Index> face;
-  const char* p = text.data();
-  const char* file_end = p + text.size();
-  while (p < file_end) {
-    const char* nl = (const char*)std::memchr(p, '\n', (size_t)(file_end - p));
-    Cursor c{p, nl ? nl : file_end};
-    p = nl ? nl + 1 : file_end;
-    line_no++;
-    const char *kb, *ke;
-    if (!c.token(kb, ke) || *kb == '#') continue;
-    const size_t klen = (size_t)(ke - kb);
-    auto key_is = [&](const char* k) { return std::strlen(k) == klen && std::memcmp(kb, k, klen) == 0; };
-    if (key_is("v")) {
-      float x = c.real(), y = c.real(), z = c.real();
-      v.insert(v.end(), {x, y, z});
-    } else if (key_is("vt")) {
-      float a = c.real(), b = c.real();
-      vt.insert(vt.end(), {a, b});
-    } else if (key_is("vn")) {
-      float x = c.real(), y = c.real(), z = c.real();
-      vn.insert(vn.end(), {x, y, z});
-    } else if (key_is("mtllib")) {
-      const char *b, *e;
-      while (c.token(b, e)) load_mtl(mtl_search_path / std::string(b, e), out.materials, mat_by_name, out.warning);
-    } else if (key_is("usemtl")) {
-      const char *b, *e;
-      std::string name = c.token(b, e) ? std::string(b, e) : std::string();
-      auto it = mat_by_name.find(name);
-      if (it == mat_by_name.end()) { out.warning += "material [ '" + name + "' ] not found in .mtl\n"; current_material = -1; }
-      else current_material = it->second;
-    } else if (key_is("f")) {
-      face.clear();
-      const char *b, *e;
-      while (c.token(b, e)) {
-        Index idx;
-        if (!parse_index_range(b, e, (int)v.size() / 3, (int)vt.size() / 2, (int)vn.size() / 3, idx)) {
-          error = "Failed to parse `f' line (e.g. a zero or out-of-range vertex index) at line " + std::to_string(line_no) + "\n";
-          return false;
-        }
-        face.push_back(idx);
-      }
-      if (face.size() < 3) { out.warning += "Degenerated face found\n."; continue; }
-      int tris[2][3];
-      int n_tris = 0;
-      auto emit = [&](int a, int b2, int c2) {
-        const int t[3] = {a, b2, c2};
-        for (int k = 0; k < 3; k++) {
-          const Index& idx = face[(size_t)t[k]];
-          ObjVertex ov;
-          for (int ax = 0; ax < 3; ax++) ov.pos[ax] = v[3 * (size_t)(idx.v - 1) + ax];
-          if (idx.vt > 0) { ov.uv[0] = vt[2 * (size_t)(idx.vt - 1)]; ov.uv[1] = vt[2 * (size_t)(idx.vt - 1) + 1]; ov.has_uv = true; }
-          if (idx.vn > 0) { for (int ax = 0; ax < 3; ax++) ov.normal[ax] = vn[3 * (size_t)(idx.vn - 1) + ax]; ov.has_normal = true; }
-          out.vertices.push_back(ov);
-        }
-        out.material_ids.push_back(current_material);
-      };
-      if (face.size() == 3) {
-        emit(0, 1, 2);
-      } else if (face.size() == 4) {
-        // split along the shorter diagonal; on a tie take [0,1,3],[1,2,3] (float arithmetic, as tinyobj)
-        const float* p0 = &v[3 * (size_t)(face[0].v - 1)];
-        const float* p1 = &v[3 * (size_t)(face[1].v - 1)];
-        const float* p2 = &v[3 * (size_t)(face[2].v - 1)];
-        const float* p3 = &v[3 * (size_t)(face[3].v - 1)];
-        float e02x = p2[0] - p0[0], e02y = p2[1] - p0[1], e02z = p2[2] - p0[2];
-        float e13x = p3[0] - p1[0], e13y = p3[1] - p1[1], e13z = p3[2] - p1[2];
-        float sqr02 = e02x * e02x + e02y * e02y + e02z * e02z;
-        float sqr13 = e13x * e13x + e13y * e13y + e13z * e13z;
-        if (sqr02 < sqr13) { tris[0][0] = 0; tris[0][1] = 1; tris[0][2] = 2; tris[1][0] = 0; tris[1][1] = 2; tris[1][2] = 3; }
-        else { tris[0][0] = 0; tris[0][1] = 1; tris[0][2] = 3; tris[1][0] = 1; tris[1][1] = 2; tris[1][2] = 3; }
-        n_tris = 2;
-        for (int t = 0; t < n_tris; t++) emit(tris[t][0], tris[t][1], tris[t][2]);
+  for (Chunk& c : chunks) {
+    c.material_at_start = current_material;
+    for (Chunk::Event& ev : c.events) {
+      if (ev.is_lib) {
+        for (const std::string& name : ev.names) load_mtl(mtl_search_path / name, out.materials, mat_by_name, out.warning);
       } else {
-        for (size_t k = 1; k + 1 < face.size(); k++) emit(0, (int)k, (int)k + 1);
+        auto it = mat_by_name.find(ev.names[0]);
+        if (it == mat_by_name.end()) { out.warning += "material [ '" + ev.names[0] + "' ] not found in .mtl\n"; current_material = -1; }
+        else current_material = it->second;
+        ev.material = current_material;
       }
     }
+  }
+  std::vector<float> v(nv), vt(nvt), vn(nvn);
+  run_on_threads(n_chunks, [&](size_t i) {
+    const Chunk& c = chunks[i];
+    if (!c.v.empty()) std::memcpy(&v[3 * c.v_before], c.v.data(), c.v.size() * sizeof(float));
+    if (!c.vt.empty()) std::memcpy(&vt[2 * c.vt_before], c.vt.data(), c.vt.size() * sizeof(float));
+    if (!c.vn.empty()) std::memcpy(&vn[3 * c.vn_before], c.vn.data(), c.vn.size() * sizeof(float));
+  });
+  lap("gather");
+  out.vertices.resize(3 * tris);
+  out.material_ids.resize(tris);
+  lap("resize");
+  run_on_threads(n_chunks, [&](size_t i) { emit_chunk(chunks[i], v, vt, vn, out); });
+  lap("pass 2");
+
+  // the first bad `f` line in file order, whether its syntax or its indices were at fault
+  for (const Chunk& c : chunks) {
+    size_t bad = 0;
+    if (c.error_line && c.range_error_line) bad = std::min(c.error_line, c.range_error_line);
+    else bad = c.error_line ? c.error_line : c.range_error_line;
+    if (bad) {
+      error = "Failed to parse `f' line (e.g. a zero or out-of-range vertex index) at line " + std::to_string(c.lines_before + bad) + "\n";
+      return false;
+    }
+    out.warning += c.warning;
   }
   return true;
 }

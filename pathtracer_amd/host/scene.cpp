@@ -1,6 +1,7 @@
 // Scene on top of the C ABI (include/ptk.h).
 #include "scene.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <iostream>
 
@@ -98,10 +99,19 @@ std::vector<Primitive> Scene::load_obj(const std::filesystem::path& filename)
 
   pt::ObjMesh mesh;
   std::string error;
+  const bool timing = std::getenv("PT_TIMING") != nullptr;  // prints where a large file's load time goes
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t1 = std::chrono::steady_clock::now();
+    std::cerr << "[pt load_obj] " << what << ": " << std::chrono::duration<double>(t1 - t0).count() << " s" << std::endl;
+    t0 = t1;
+  };
   if (!pt::load_obj_file(filename, mtl_search_path, mesh, error)) {
     if (!error.empty()) std::cerr << __FUNCTION__ << " " << error;
     std::exit(1);  // as the reference does (src/scene.cpp:103-108)
   }
+  lap("parse");
   if (!mesh.warning.empty()) std::cout << __FUNCTION__ << " " << mesh.warning;
   std::cout << __FUNCTION__ << " Materials: " << mesh.materials.size() << std::endl;
 
@@ -160,6 +170,7 @@ std::vector<Primitive> Scene::load_obj(const std::filesystem::path& filename)
       triangles.push_back(Primitive(tri, &m_materials[offset + (size_t)mid]));
     }
   }
+  lap("primitives");
   std::cout << __FUNCTION__ << " Triangles: " << triangles.size() << std::endl;
   return triangles;
 }

@@ -3,6 +3,7 @@ command-line driver end to end (JSON config -> Scene / Camera / Renderer -> PNG)
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -228,3 +229,54 @@ def test_grid_boxes_contain_their_primitives(scene_name):
     assert r["violations"] == 0, r
     assert r["reached"] == info["n_prims"], (r, info)
     assert r["deepest"] == info["max_depth"] <= 25, (r, info)
+
+
+def test_obj_loader_pieces_give_the_single_thread_result(host, tmp_path, monkeypatch):
+    """Files above 4 MB are parsed in pieces by several threads.  Relative indices, usemtl switches and polygons
+    next to the piece borders must come out exactly as from one thread; an out-of-range index is reported with
+    its line number whichever piece holds it."""
+    rng = np.random.RandomState(1)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nnewmtl b\nKd 0 1 0\nKe 1 1 1\n")
+    lines, nv = ["mtllib m.mtl"], 0
+    for blk in range(40000):
+        k = int(rng.randint(3, 7))
+        for _ in range(k):
+            lines.append("v %.5f %.5f %.5f" % tuple(rng.uniform(-1, 1, 3)))
+            lines.append("vt %.4f %.4f" % tuple(rng.uniform(0, 1, 2)))
+        nv += k
+        if blk % 7 == 0:
+            lines.append("usemtl " + ("a" if (blk // 7) % 2 else "b"))
+        if blk % 3 == 0:
+            lines.append("f " + " ".join("%d/%d" % (-k + j, -k + j) for j in range(k)))
+        else:
+            lines.append("f " + " ".join("%d/%d" % (nv - k + j + 1, nv - k + j + 1) for j in range(k)))
+    text = "\n".join(lines) + "\n"
+    assert len(text) > (4 << 20)
+    (tmp_path / "t.obj").write_text(text)
+
+    def load(threads):
+        monkeypatch.setenv("PT_LOAD_THREADS", str(threads))
+        n = 110000
+        a = [np.zeros((n, 9)), np.zeros((n, 9)), np.zeros((n, 6)), np.zeros(n, np.int32), np.zeros((n, 3)), np.zeros((n, 3)),
+             np.zeros(n, np.int32)]
+        nl = C.c_int()
+        r = host.pt_host_load_obj(str(tmp_path / "t.obj").encode(), n, *[x.ctypes.data for x in a], C.byref(nl))
+        return r, nl.value, [x[:r].copy() for x in a]
+
+    one = load(1)
+    assert one[0] > 90000 and one[1] > 0
+    for threads in (5, 16):
+        many = load(threads)
+        assert many[0] == one[0] and many[1] == one[1]
+        for x, y in zip(many[2], one[2]):
+            assert np.array_equal(x, y)
+
+    # a bad reference deep in the file: the process exits like the reference's loader, naming the line
+    bad_line = len(lines) - 1000
+    lines.insert(bad_line, "f 1 2 99999999")
+    (tmp_path / "bad.obj").write_text("\n".join(lines) + "\n")
+    code = ("import ctypes as C; L = C.CDLL(%r); L.pt_host_load_obj.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 8; "
+            "L.pt_host_load_obj(%r, 0, *[None] * 8)" % (HOST_LIB, str(tmp_path / "bad.obj").encode()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PT_LOAD_THREADS="8"))
+    assert r.returncode == 1 and ("at line %d" % (bad_line + 1)) in r.stderr, r.stderr[-300:]

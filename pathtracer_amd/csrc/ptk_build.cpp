@@ -462,7 +462,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     for (int k = 0; k < 3; k++) { e1[k] = (float)(p[3 + k] - (double)v0[k]); e2[k] = (float)(p[6 + k] - (double)v0[k]); }
     r.a = f4{v0[0], v0[1], v0[2], e1[0]};
     r.b = f4{e1[1], e1[2], e2[0], e2[1]};
-    r.c = f4{e2[2], as_float((uint32_t)i), as_float((uint32_t)kTriangle), 0.f};
+    r.c = f4{e2[2], as_float((uint32_t)i), 0.f, 0.f};
     Box& b = boxes[i];
     for (int a = 0; a < 3; a++) {
       b.lo[a] = f_down(std::min(p[a], std::min(p[3 + a], p[6 + a])));
@@ -518,7 +518,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     PrimRec& r = by_id[i];
     r.a = f4{(float)c[0], (float)c[1], (float)c[2], (float)rad};
     r.b = f4{0.f, 0.f, 0.f, 0.f};
-    r.c = f4{0.f, as_float((uint32_t)i), as_float((uint32_t)kSphere), 0.f};
+    r.c = f4{0.f, as_float((uint32_t)i | kPrimSphereBit), 0.f, 0.f};
     Box& b = boxes[i];
     for (int a = 0; a < 3; a++) {
       b.lo[a] = f_down(c[a] - std::fabs(rad));
@@ -684,7 +684,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   lap("flatten");
   if (!cache_file.empty()) {
     std::vector<uint32_t> order((size_t)n);
-    for (int i = 0; i < n; i++) order[i] = as_uint(out.prims[i].c.y);
+    for (int i = 0; i < n; i++) order[i] = as_uint(out.prims[i].c.y) & kPrimIdMask;
     cache_store(cache_file, cache_key, out.nodes, order, out.max_depth, out.max_leaf);
     lap("cache written");
   }

@@ -80,9 +80,11 @@ PTK_HD void set_child_box(NodePair& n, int which, const float lo[3], const float
 enum PrimKind : uint32_t { kTriangle = 0, kSphere = 1 };
 
 // Intersection record, stored in BVH leaf order.
-//   triangle: a = (v0.x, v0.y, v0.z, e1.x)  b = (e1.y, e1.z, e2.x, e2.y)  c = (e2.z, id, kind, 0)
-//   sphere:   a = (c.x, c.y, c.z, radius)   b = unused                    c = (0,    id, kind, 0)
-// id is the reference's primitive id (insertion order, src/scene.cpp:59).
+//   triangle: a = (v0.x, v0.y, v0.z, e1.x)  b = (e1.y, e1.z, e2.x, e2.y)  c = (e2.z, id,                  -, -)
+//   sphere:   a = (c.x, c.y, c.z, radius)   b = unused                    c = (0,    id | kPrimSphereBit, -, -)
+// id is the reference's primitive id (insertion order, src/scene.cpp:59).  The traversal fetches 40 bytes.
+constexpr uint32_t kPrimSphereBit = 0x80000000u;
+constexpr uint32_t kPrimIdMask = 0x7fffffffu;
 struct alignas(16) PrimRec {
   f4 a, b, c;
 };

@@ -184,12 +184,18 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   // (loaded whole, by value: the child links must not become a second, dependent fetch)
   const NodePair n = *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) +
                                                          ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)));
-#ifdef PTK_EXTRA_LOAD  // experiment: one more cache access per node visit, result unused
+#ifdef PTK_EXTRA_LOAD  // experiment: one more 16-byte cache access per node visit, result unused
   {
-    const volatile int32_t* extra = reinterpret_cast<const volatile int32_t*>(reinterpret_cast<const char*>(sc.nodes) +
-                                                                             ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)) + 28);
-    int32_t x = *extra;
-    asm volatile("" ::"v"(x));
+    // 1: at the lane's own node; 2: lanes 2k and 2k+1 read the two adjacent halves of lane 2k's node
+    uint32_t off = (uint32_t)tr.node * (uint32_t)sizeof(NodePair);
+#if PTK_EXTRA_LOAD == 2 && defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t partner = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+    const bool odd = (threadIdx.x & 1u) != 0;
+    off = odd ? partner + 16u : off;
+#endif
+    const volatile f4* extra = reinterpret_cast<const volatile f4*>(reinterpret_cast<const char*>(sc.nodes) + off);
+    float x = extra->x, y = extra->w;
+    asm volatile("" ::"v"(x), "v"(y));
   }
 #endif
 #ifdef PTK_BURN_INNER
@@ -222,14 +228,15 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
 template <bool STATS>
 PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
 {
-  const uint32_t id = as_uint(p.c.y), kind = as_uint(p.c.z);
+  // id and kind share a word (PrimRec), which makes the record's third load 8 bytes instead of 12
+  const uint32_t idw = as_uint(p.c.y), id = idw & kPrimIdMask;
   if (STATS) cnt.prim_tests++;
 #ifdef PTK_BURN_PRIM
   for (int burn = 0; burn < PTK_BURN_PRIM; burn++) PTK_BURN12(tr.node);
 #endif
   float t = 0.0f, u = 0.0f, v = 0.0f;
   bool ok;
-  if (kind == kTriangle) {
+  if ((idw & kPrimSphereBit) == 0u) {
     // a triangle the ray starts on is not a candidate (see the note at the top of this file)
     ok = hit_triangle(p, tr.o, tr.d, tr.hit.t, t, u, v) & (id != tr.skip_id);
   } else {

@@ -105,7 +105,7 @@ void hc_tree_check(void* h, int64_t* out)
     for (uint32_t i = first; i < first + count && i < hs.prims.size(); i++) {
       const PrimRec& p = hs.prims[i];
       double lo[3], hi[3];
-      if (as_uint(p.c.z) == kTriangle) {
+      if ((as_uint(p.c.y) & kPrimSphereBit) == 0u) {
         const double v0[3] = {p.a.x, p.a.y, p.a.z}, e1[3] = {p.a.w, p.b.x, p.b.y}, e2[3] = {p.b.z, p.b.w, p.c.x};
         for (int k = 0; k < 3; k++) {
           lo[k] = std::min(v0[k], std::min(v0[k] + e1[k], v0[k] + e2[k]));

@@ -13,7 +13,8 @@
 //      counter per level (the number of nodes so far) - at most kMaxTreeDepth small copies.
 //   4. fit_level_kernel, deepest level first: child boxes from the primitives' boxes (leaves) or from
 //      the child's own record (inner nodes); subtrees of at most kMaxLeafSize primitives are merged into one
-//      leaf where the surface-area heuristic prefers that.
+//      leaf where the surface-area heuristic prefers that, and the four grandchildren of a node are paired
+//      anew where another pairing has less surface area (regroup).
 //   5. number_level_kernel, top level first, gives the nodes still in use their final depth-first positions
 //      (from the subtree sizes the fitting pass left); compact_kernel moves them there and renumbers the links; gather_kernel: primitive records into leaf order.
 #include "ptk_lbvh.h"
@@ -142,6 +143,10 @@ __device__ inline float q_half_area(const QBox& b, const BoxGrid& g)
 }
 
 constexpr float kTraversalCost = 1.0f, kIntersectCost = 1.2f;  // the host builder's constants
+#ifndef PTK_LBVH_MERGE_BIAS
+#define PTK_LBVH_MERGE_BIAS 1.0f
+#endif
+constexpr float kMergeBias = PTK_LBVH_MERGE_BIAS;  // < 1: fewer, smaller leaves
 
 // Box of the child behind `link`.  An inner child whose own children are both leaves, of at most
 // kMaxLeafSize primitives together, is replaced by one leaf when testing all of them costs no more
@@ -168,15 +173,53 @@ __device__ inline QBox child_box(int32_t& link, const float* __restrict__ boxes,
     if (c.child0 < 0 && c.child1 < 0) {
       const uint32_t l0 = ~(uint32_t)c.child0, l1 = ~(uint32_t)c.child1;
       const uint32_t n0 = (l0 & 7u) + 1u, n1 = (l1 & 7u) + 1u;
-      if (n0 + n1 <= (uint32_t)kMaxLeafSize) {  // the two ranges are adjacent: l1 starts where l0 ends
+      // one leaf needs one range: l1 has to start where l0 ends (always so unless regroup() moved a leaf here)
+      if (n0 + n1 <= (uint32_t)kMaxLeafSize && (l1 >> 3) == (l0 >> 3) + n0) {
         const float a = q_half_area(r, g);
         const float split = kTraversalCost * a + kIntersectCost * (q_half_area(b0, g) * (float)n0 + q_half_area(b1, g) * (float)n1);
         const float leaf = kIntersectCost * a * (float)(n0 + n1);
-        if (leaf <= split) link = leaf_link(l0 >> 3, n0 + n1);
+        if (leaf <= kMergeBias * split) link = leaf_link(l0 >> 3, n0 + n1);
       }
     }
   }
   return r;
+}
+
+__device__ inline float pair_area(const QBox& p, const QBox& q, const BoxGrid& g)
+{
+  const QBox u{q_union(p.x, q.x), q_union(p.y, q.y), q_union(p.z, q.z)};
+  return q_half_area(u, g);
+}
+
+// The sort order decides which two grandchildren share a child; where another pairing of the four gives
+// the two children less surface area together, they are regrouped.  Depths stay as they are (grandchildren
+// remain grandchildren), so the level lists and the depth limit are not affected.  l and r are inner
+// nodes that have been fitted already and belong to the calling thread's node alone.
+__device__ inline void regroup(NodePair* nodes, int32_t l, int32_t r, uint32_t* __restrict__ subtree, const BoxGrid& g)
+{
+  NodePair L = nodes[l], R = nodes[r];
+  struct Part {
+    int32_t link;
+    QBox box;
+  };
+  Part a{L.child0, {L.x0, L.y0, L.z0}}, b{L.child1, {L.x1, L.y1, L.z1}};
+  Part c{R.child0, {R.x0, R.y0, R.z0}}, d{R.child1, {R.x1, R.y1, R.z1}};
+  const float now = pair_area(a.box, b.box, g) + pair_area(c.box, d.box, g);
+  const float ac_bd = pair_area(a.box, c.box, g) + pair_area(b.box, d.box, g);
+  const float ad_cb = pair_area(a.box, d.box, g) + pair_area(c.box, b.box, g);
+  const float best = fminf(ac_bd, ad_cb);
+  if (!(best < 0.98f * now)) return;
+  Part t = b;
+  if (ac_bd <= ad_cb) { b = c; c = t; }  // (a, c) and (b, d)
+  else { b = d; d = t; }                 // (a, d) and (c, b)
+  L.child0 = a.link; L.x0 = a.box.x; L.y0 = a.box.y; L.z0 = a.box.z;
+  L.child1 = b.link; L.x1 = b.box.x; L.y1 = b.box.y; L.z1 = b.box.z;
+  R.child0 = c.link; R.x0 = c.box.x; R.y0 = c.box.y; R.z0 = c.box.z;
+  R.child1 = d.link; R.x1 = d.box.x; R.y1 = d.box.y; R.z1 = d.box.z;
+  nodes[l] = L;
+  nodes[r] = R;
+  subtree[l] = 1u + (a.link >= 0 ? subtree[a.link] : 0u) + (b.link >= 0 ? subtree[b.link] : 0u);
+  subtree[r] = 1u + (c.link >= 0 ? subtree[c.link] : 0u) + (d.link >= 0 ? subtree[d.link] : 0u);
 }
 
 // Nodes [begin, end) are one level; every deeper level has been fitted already.
@@ -188,6 +231,9 @@ __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __r
   uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= end) return;
   int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
+#ifndef PTK_LBVH_NO_REGROUP
+  if (c0 >= 0 && c1 >= 0) regroup(nodes, c0, c1, subtree, g);
+#endif
   const QBox b0 = child_box(c0, boxes, order, nodes, g), b1 = child_box(c1, boxes, order, nodes, g);
   nodes[i].child0 = c0;
   nodes[i].child1 = c1;

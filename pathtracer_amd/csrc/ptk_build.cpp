@@ -75,9 +75,15 @@ struct Builder {
   std::vector<BuildNode> nodes;  // sized for the worst case up front so that threads never reallocate it
   std::atomic<int32_t> n_nodes{0};
   std::atomic<int> max_depth{0}, max_leaf{0};
+  std::atomic<bool> out_of_slots{false};
   static constexpr int kParallelMin = 16384;  // smaller sides are not worth a thread
+  static constexpr int kMaxThreads = 64;
 
-  explicit Builder(const std::vector<Box>& b)
+  // Slot budget: every range that one thread builds alone takes a block of 2 * count slots (its subtree has at
+  // most 2 * count - 1 nodes) and those ranges are disjoint, so the blocks sum to at most 2 * n.  Nodes above
+  // the blocks (built while the range can still be shared between threads) take one slot each: they form a
+  // tree with at most `threads` ends whose root paths are at most kMaxTreeDepth + 1 long.
+  Builder(const std::vector<Box>& b, int threads)
   {
     size_t n = b.size();
     items.resize(n);
@@ -86,7 +92,7 @@ struct Builder {
       items[i].id = (int32_t)i;
       for (int a = 0; a < 3; a++) items[i].centroid[a] = 0.5f * (b[i].lo[a] + b[i].hi[a]);
     }
-    nodes.resize(2 * n + 64);  // blocks of 2 * count per single-thread subtree + the few nodes above them
+    nodes.resize(2 * n + (size_t)std::max(threads, 1) * (kMaxTreeDepth + 2) + 64);
   }
 
   static void raise(std::atomic<int>& m, int v)
@@ -111,12 +117,18 @@ struct Builder {
   int32_t build(int first, int count, int depth, int threads, Block* block = nullptr)
   {
     Block own;
-    if (!block && threads <= 1) {  // from here down this thread works alone: at most 2 * count - 1 nodes
+    // From here down this thread works alone (a split is shared between threads only when both sides hold
+    // kParallelMin primitives, which a range below twice that cannot give): at most 2 * count - 1 nodes.
+    if (!block && (threads <= 1 || count < 2 * kParallelMin)) {
       own.next = n_nodes.fetch_add(2 * count);
       own.end = own.next + 2 * count;
       block = &own;
     }
     int32_t ni = block ? block->next++ : n_nodes.fetch_add(1);
+    if (ni < 0 || (size_t)ni >= nodes.size() || (block && ni >= block->end)) {  // never write outside the array
+      out_of_slots.store(true);
+      return 0;
+    }
     Box box, cbox;
     box.reset(); cbox.reset();
     for (int i = first; i < first + count; i++) {
@@ -488,7 +500,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     int shares = 1;
     if (d.n_triangles >= 65536) {
       shares = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-      if (const char* e = getenv("PTK_BUILD_THREADS")) shares = std::max(1, atoi(e));
+      if (const char* e = getenv("PTK_BUILD_THREADS")) shares = std::min(std::max(1, atoi(e)), 64);
     }
     std::vector<Share> share(shares);
     std::vector<std::thread> workers;
@@ -611,12 +623,13 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     out.nodes.clear();
     lap("cache miss");
   }
-  Builder bld(boxes);
-  lap("centroids");
   // 16 = one GPU's share of a node's host cores (std::thread::hardware_concurrency() sees the whole node)
   int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  if (const char* e = getenv("PTK_BUILD_THREADS")) threads = std::max(1, atoi(e));
+  if (const char* e = getenv("PTK_BUILD_THREADS")) threads = std::min(std::max(1, atoi(e)), Builder::kMaxThreads);
+  Builder bld(boxes, threads);
+  lap("centroids");
   bld.build(0, n, 0, threads);
+  if (bld.out_of_slots.load()) return "internal: BVH builder ran out of node slots";
   bld.finish();
   lap("tree");
   out.max_depth = bld.max_depth;

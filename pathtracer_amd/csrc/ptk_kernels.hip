@@ -698,15 +698,18 @@ int ptk_set_camera(ptk_ctx* ctx, const ptk_camera* camera)
   PTK_HIP(hipStreamSynchronize(ctx->stream));
   size_t pixels = (size_t)camera->width * (size_t)camera->height;
   if (pixels != ctx->accum_pixels || !ctx->d_accum_own) {
-    bool bound = ctx->d_accum && ctx->d_accum != ctx->d_accum_own;
     if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
+    // nothing may point at the freed buffer if the allocation below fails
     ctx->d_accum_own = nullptr;
+    ctx->d_accum = nullptr;
+    ctx->accum_pixels = 0;
+    ctx->have_camera = false;
     PTK_HIP(hipMalloc((void**)&ctx->d_accum_own, pixels * sizeof(f4)));
     ctx->accum_pixels = pixels;
-    if (!bound) ctx->d_accum = ctx->d_accum_own;
-    else ctx->d_accum = ctx->d_accum_own;  // a bound buffer of another size is no longer valid
+    ctx->d_accum = ctx->d_accum_own;  // a caller's buffer bound for another image size is no longer valid
   }
-  PTK_HIP(hipMemsetAsync(ctx->d_accum_own, 0, pixels * sizeof(f4), ctx->stream));
+  // the buffer in use is cleared, whether it is the context's own or one the caller bound (same size)
+  PTK_HIP(hipMemsetAsync(ctx->d_accum, 0, pixels * sizeof(f4), ctx->stream));
   ctx->cam = make_camera_view(*camera);
   ctx->have_camera = true;
   return PTK_OK;

@@ -143,7 +143,7 @@ bool decode_jpeg(const std::vector<uint8_t>& f, int& width, int& height, std::ve
       while (i < n) {
         int pq = s[i] >> 4, tq = s[i] & 15;
         i++;
-        if (tq > 3) { why = "bad JPEG quantisation table"; return false; }
+        if (tq > 3 || pq > 1 || i + (pq ? 128u : 64u) > n) { why = "bad JPEG quantisation table"; return false; }
         for (int k = 0; k < 64; k++) {
           if (pq) { qt[tq][kZigzag[k]] = (uint16_t)((s[i] << 8) | s[i + 1]); i += 2; }
           else qt[tq][kZigzag[k]] = s[i++];
@@ -164,11 +164,13 @@ bool decode_jpeg(const std::vector<uint8_t>& f, int& width, int& height, std::ve
         h.build();
       }
     } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+      if (n < 6) { why = "truncated JPEG frame header"; return false; }
       if (s[0] != 8) { why = "only 8-bit JPEG is supported"; return false; }
       height = (s[1] << 8) | s[2];
       width = (s[3] << 8) | s[4];
       int nc = s[5];
       if (width <= 0 || height <= 0 || (nc != 1 && nc != 3)) { why = "unsupported JPEG frame"; return false; }
+      if (n < 6 + 3 * (size_t)nc) { why = "truncated JPEG frame header"; return false; }
       comps.resize(nc);
       for (int i = 0; i < nc; i++) {
         comps[i].id = s[6 + 3 * i];
@@ -184,18 +186,29 @@ bool decode_jpeg(const std::vector<uint8_t>& f, int& width, int& height, std::ve
       why = "progressive / arithmetic / lossless JPEG is not supported";
       return false;
     } else if (marker == 0xDD) {
+      if (n < 2) { why = "truncated JPEG restart interval"; return false; }
       restart_interval = (s[0] << 8) | s[1];
     } else if (marker == 0xDA) {  // SOS: entropy-coded data follows
       if (!have_frame) { why = "JPEG scan before frame header"; return false; }
+      if (n < 1) { why = "truncated JPEG scan header"; return false; }
       int ns = s[0];
       if (ns != (int)comps.size()) { why = "non-interleaved JPEG scans are not supported"; return false; }
+      if (n < 1 + 2 * (size_t)ns + 3) { why = "truncated JPEG scan header"; return false; }
       for (int i = 0; i < ns; i++) {
         int cid = s[1 + 2 * i];
+        int td = s[2 + 2 * i] >> 4, ta = s[2 + 2 * i] & 15;
+        if (td > 3 || ta > 3) { why = "bad JPEG Huffman table selector"; return false; }  // they index dc[4] / ac[4]
         for (auto& c : comps)
-          if (c.id == cid) { c.td = s[2 + 2 * i] >> 4; c.ta = s[2 + 2 * i] & 15; }
+          if (c.id == cid) { c.td = td; c.ta = ta; }
       }
       int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
       int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
+      // A damaged frame header must not turn into a huge allocation: every coded 8x8 block takes at least
+      // two bits (one DC and one AC code).
+      if ((uint64_t)width * (uint64_t)height > (1ull << 28) || (uint64_t)mcus_x * (uint64_t)mcus_y / 4 > f.size() - (pos + len)) {
+        why = "JPEG frame size does not fit its data";
+        return false;
+      }
       for (auto& c : comps) {
         c.blocks_w = mcus_x * c.h;
         c.blocks_h = mcus_y * c.v;

@@ -55,10 +55,16 @@ bool decode_png(const std::vector<uint8_t>& f, int& width, int& height, std::vec
     case 6: channels = 4; break;
     default: why = "bad PNG colour type"; return false;
   }
-  if (!(bit_depth == 8 || bit_depth == 16 || (bit_depth < 8 && (color_type == 0 || color_type == 3)))) { why = "unsupported PNG bit depth"; return false; }
+  const bool small_depth = bit_depth == 1 || bit_depth == 2 || bit_depth == 4;  // the only depths below 8 that PNG defines
+  if (!(bit_depth == 8 || (bit_depth == 16 && color_type != 3) || (small_depth && (color_type == 0 || color_type == 3)))) { why = "unsupported PNG bit depth"; return false; }
   size_t bits_per_pixel = (size_t)channels * (size_t)bit_depth;
   size_t row_bytes = ((size_t)width * bits_per_pixel + 7) / 8;
   size_t bpp = bits_per_pixel < 8 ? 1 : bits_per_pixel / 8;  // filter distance
+  // A damaged header must not turn into a huge allocation: deflate expands by at most about 1032 times.
+  if ((uint64_t)width * (uint64_t)height > (1ull << 28) || (row_bytes + 1) * (size_t)height > 1040 * idat.size() + 64) {
+    why = "PNG image size does not fit its data";
+    return false;
+  }
   std::vector<uint8_t> raw((row_bytes + 1) * (size_t)height);
   uLongf out_len = (uLongf)raw.size();
   int zr = uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size());

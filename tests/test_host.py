@@ -280,3 +280,69 @@ def test_obj_loader_pieces_give_the_single_thread_result(host, tmp_path, monkeyp
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, PT_LOAD_THREADS="8"))
     assert r.returncode == 1 and ("at line %d" % (bad_line + 1)) in r.stderr, r.stderr[-300:]
+
+
+def test_threaded_tree_builder_under_address_sanitizer(tmp_path):
+    """The host builder hands node slots to its threads from one array sized up front.  With 16 or more
+    threads (the default on the GPU box) uniform random triangles used to push the nodes built above the
+    per-thread blocks past the end of that array; the builder is compiled here with the address sanitizer and
+    run at the thread counts and sizes that overflowed."""
+    exe = tmp_path / "build_stress"
+    src = [os.path.join(ROOT, "tests", "hostcheck", "build_stress.cpp"), os.path.join(ROOT, "pathtracer_amd", "csrc", "ptk_build.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-pthread", "-o", str(exe)] + src)
+    for n, threads, crowd in ((140000, 16, 0), (200000, 24, 0), (300000, 32, 0), (200000, 64, 1)):
+        r = subprocess.run([str(exe), str(n), "3", str(crowd)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, PTK_BUILD_THREADS=str(threads)))
+        assert r.returncode == 0 and r.stdout.startswith("ok"), (n, threads, r.stdout[-200:], r.stderr[-600:])
+
+
+def test_image_decoders_reject_damaged_files_under_address_sanitizer(tmp_path):
+    """Asset files are untrusted input: truncated segments, Huffman table selectors above 3, quantisation
+    tables cut short and PNG bit depths that the format does not define must be refused, never read out of
+    bounds.  The decoders are compiled with the address and undefined-behaviour sanitizers and fed damaged files."""
+    exe = tmp_path / "codec_fuzz"
+    host_dir = os.path.join(ROOT, "pathtracer_amd", "host")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-fno-omit-frame-pointer", "-o", str(exe), os.path.join(ROOT, "tests", "hostcheck", "codec_fuzz.cpp"),
+                           os.path.join(host_dir, "codec_jpeg.cpp"), os.path.join(host_dir, "codec_png.cpp"), "-lz"])
+    rng = np.random.RandomState(7)
+    ys, xs = np.mgrid[0:24, 0:40]
+    img = Image.fromarray(np.clip(np.stack([128 + 100 * np.sin(xs / 5.0), 128 + 90 * np.cos(ys / 4.0), 60 + xs * 4.0], -1), 0, 255).astype(np.uint8))
+    jpg, png, pal = tmp_path / "a.jpg", tmp_path / "a.png", tmp_path / "p.png"
+    img.save(jpg, quality=85, subsampling=2)
+    img.save(png)
+    img.quantize(16).save(pal, bits=4)
+    files = []
+
+    def emit(name, data):
+        p = tmp_path / name
+        p.write_bytes(bytes(data))
+        files.append(str(p))
+
+    for src in (jpg, png, pal):
+        raw = src.read_bytes()
+        emit("whole_" + src.name, raw)
+        for cut in sorted(set(list(range(0, min(len(raw), 700), 3)) + [len(raw) - k for k in range(1, 40)])):
+            emit(f"cut{cut}_{src.name}", raw[:cut])
+        for k in range(300):
+            b = bytearray(raw)
+            for _ in range(int(rng.randint(1, 4))):
+                b[int(rng.randint(2, len(b)))] = int(rng.randint(0, 256))
+            emit(f"mut{k}_{src.name}", b)
+    raw = bytearray(jpg.read_bytes())
+    sos = raw.find(b"\xff\xda")
+    assert sos > 0
+    for sel in (0x40, 0x0f, 0xff):  # table selectors index four-entry arrays
+        b = bytearray(raw)
+        b[sos + 6] = sel
+        emit(f"sel{sel}.jpg", b)
+    for depth in (3, 5, 6, 7):  # not PNG bit depths: would make the sample shift negative
+        b = bytearray(pal.read_bytes())
+        b[24] = depth
+        emit(f"depth{depth}.png", b)
+    for i in range(0, len(files), 400):
+        r = subprocess.run([str(exe)] + files[i:i + 400], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout[-300:], r.stderr[-1500:])
+    first = subprocess.run([str(exe), files[0], str(tmp_path / "sel64.jpg"), str(tmp_path / "depth3.png")], capture_output=True, text=True)
+    assert "decoded 1 rejected 2" in first.stdout, first.stdout

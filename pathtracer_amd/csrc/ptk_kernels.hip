@@ -152,23 +152,36 @@ __device__ __forceinline__ int interleave_rows(int v, int n)
   return (v % q) * 8 + r + v / q;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+// Sum of a per-lane 32-bit count over the wave, in 64 bits (64 lanes of up to 2^32 - 1 each).
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v)
 {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  unsigned long long s = v;
+  for (int off = 32; off > 0; off >>= 1) s += (unsigned long long)__shfl_xor((long long)s, off, 64);
+  return s;
 }
 
 __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* out)
 {
-  uint32_t a = wave_sum(c.camera_rays), b = wave_sum(c.segments), q = wave_sum(c.queries);
-  uint32_t x = wave_sum(c.box_tests), p = wave_sum(c.prim_tests);
+  unsigned long long a = wave_sum(c.camera_rays), b = wave_sum(c.segments), q = wave_sum(c.queries);
+  unsigned long long x = wave_sum(c.box_tests), p = wave_sum(c.prim_tests);
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&out[0], (unsigned long long)a);
-    atomicAdd(&out[1], (unsigned long long)b);
-    atomicAdd(&out[2], (unsigned long long)q);
-    atomicAdd(&out[3], (unsigned long long)x);
-    atomicAdd(&out[4], (unsigned long long)p);
+    atomicAdd(&out[0], a);
+    atomicAdd(&out[1], b);
+    atomicAdd(&out[2], q);
+    atomicAdd(&out[3], x);
+    atomicAdd(&out[4], p);
   }
+}
+
+// The per-lane counts are 32-bit registers: a long launch empties them into the 64-bit totals whenever one
+// of them has passed 2^30 (checked where the wave hands out work items, i.e. at most a path's worth of
+// counting later), so they cannot wrap.  All 64 lanes must be active.
+__device__ __forceinline__ void flush_counters_if_large(Counters& c, unsigned long long* out)
+{
+  const uint32_t any = c.camera_rays | c.segments | c.queries | c.box_tests | c.prim_tests;
+  if (__ballot(any >= 0x40000000u) == 0ull) return;
+  flush_counters(c, out);
+  c = Counters{0, 0, 0, 0, 0};
 }
 
 template <bool STATS>
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   // Hand the next work items, in lane order, to the lanes that ask for one; repeat while a lane
   // was given an item that needs no query (a pixel slot outside the image).
   auto refill = [&](bool need) {
+    flush_counters_if_large(cnt, counters);
     for (;;) {
       unsigned long long m = __ballot(need);
       if (m == 0ull) break;

@@ -106,4 +106,18 @@ def scene(name: str):
         lamp = s.add_material(scenes.Material(albedo=(0.8, 0.8, 0.8), emission=(4.0, 3.0, 2.0)))
         s.add_sphere((0.0, 6.0, -2.0), 0.7, lamp)
         return s
+    if name == "mirror_tex":  # textured sphere (Sphere::texcoord), MIRROR-type sphere and wall, textured floor
+        s = scenes.cornell_box(48, 48, aperture=0.0, focus_distance=0.0)
+        tex = s.add_texture(scenes.procedural_texture(256, 6, seed=3))
+        globe = s.add_material(scenes.Material(albedo=(1.0, 1.0, 1.0), texture=tex))
+        s.add_sphere((2.2, 1.8, 1.0), 1.8, globe)
+        # Material::MIRROR is perfectly specular (src/material.h:30-35) but BxDF::sample / eval have no case for
+        # it (src/material.cpp:110-136): it scatters like a diffuse surface and only switches light sampling off
+        mirror = s.add_material(scenes.Material(type=scenes.MIRROR, albedo=(0.9, 0.9, 0.9), roughness=0.0))
+        s.add_sphere((-2.4, 1.5, -1.0), 1.5, mirror)
+        s.tri_mat = s.tri_mat.copy()
+        s.tri_mat[6:8] = mirror  # the right wall
+        return s
+    if name == "envmap_full":  # environment map at the size of the reference's asset (3584 x 1792, 19 MB of texels)
+        return scenes.cornell_with_mesh(3, 64, 36, envmap=scenes.procedural_envmap(3584, 1792))
     raise KeyError(name)

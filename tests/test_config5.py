@@ -1,0 +1,98 @@
+"""The largest named configuration: Cornell box + 1,310,720-triangle mesh, 3840 x 2160, shared between GPUs as
+interleaved 16-row bands.  What the oracle can check in seconds (closest hits of seeded ray batches, a band of
+rows of the 4K frame) is checked against it; the whole 4K frame is checked through properties: every pixel gets
+exactly its samples, all values finite, the same launches give the same bits, and the frame assembled from the
+eight bands shares of an 8-GPU tile split equals the one-launch frame up to fp32 summation order."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from pathtracer_amd import scenes
+from tests import parity, raygen
+from tests.backends import GpuBackend
+
+pytestmark = pytest.mark.gpu
+
+W, H = 3840, 2160
+BOUNCES = 3
+
+
+@pytest.fixture(scope="module")
+def big_scene():
+    return scenes.cornell_with_mesh(8, W, H)
+
+
+@pytest.fixture(scope="module")
+def big_oracle(big_scene):
+    return orc.OracleScene(big_scene)
+
+
+@pytest.fixture(scope="module")
+def big_rays(big_oracle):
+    rays = np.concatenate([raygen.interior_rays(30000, 61), raygen.camera_like_rays(30000, 62)])
+    rays = np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
+    first, _ = big_oracle.intersect(rays)
+    # rays leaving the mesh's surface: the no-offset self-intersection rules on millimetre-sized triangles
+    on_mesh = first[(first["hit"] == 1) & (first["id"] < 1310720)][:10000]
+    sec = np.asarray(raygen.secondary_rays(on_mesh, 63), np.float64).astype(np.float32).astype(np.float64)
+    return rays, first, sec
+
+
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_million_triangle_scene_hits_match_the_oracle(gpu_ctx, big_scene, big_oracle, big_rays, builder):
+    sd = big_scene
+    b = GpuBackend(gpu_ctx, sd, builder)
+    info = b.info()
+    assert info["n_prims"] == 1310720 + 12 and info["max_depth"] <= 25 and info["max_leaf"] <= 4
+    assert info["builder"] == (1 if builder == "device" else 0)
+    rays, ref, sec = big_rays
+    got, cgot = b.intersect(rays)
+    c = parity.classify_hits(sd, rays, ref, got)
+    print(builder, info, c, {k: v / len(rays) for k, v in cgot.items()})
+    assert c["unexplained"] == 0, c
+    excused = c["tie"] + c["near"] + c["ref_miss"] + c["graze"] + c["cond"]
+    assert excused <= max(3, 1e-4 * c["n"]), c
+    assert c["max_rel_t"] <= 1e-5, c
+    rec = parity.check_hit_records(ref, got)
+    assert rec["point"] < 1e-5 and rec["material_mismatch"] == 0 and rec["normal"] < 1e-5, rec
+    ref2, _ = big_oracle.intersect(sec)
+    got2, _ = b.intersect(sec)
+    c2 = parity.classify_hits(sd, sec, ref2, got2)
+    print(builder, "secondary", c2)
+    assert c2["unexplained"] == 0, c2
+    assert c2["tie"] + c2["ref_miss"] + c2["graze"] <= max(3, 5e-4 * c2["n"]), c2
+    assert c2["near"] <= 3e-2 * c2["n"] and c2["cond"] <= 2e-3 * c2["n"], c2
+
+
+def test_4k_frame_as_eight_band_shares(gpu_ctx, big_scene, big_oracle):
+    sd = big_scene
+    b = GpuBackend(gpu_ctx, sd)
+    spp = 4
+    one, cnt = b.render(spp, BOUNCES, seed=71, collect_stats=False)
+    _, total = gpu_ctx.read_accum()
+    assert one.shape == (H, W, 3) and total == spp
+    assert np.isfinite(one).all() and one.min() >= 0.0 and one.max() > 1.0
+    assert cnt["camera_rays"] == W * H * spp
+    again, cnt2 = b.render(spp, BOUNCES, seed=71, collect_stats=False)
+    assert np.array_equal(one, again) and cnt == cnt2
+    # the shares of eight GPUs (bands of 16 rows, band k to GPU k % 8), one launch each, into one buffer
+    rays = 0
+    for first in range(8):
+        banded, c = b.render(spp, BOUNCES, seed=71, band_rows=16, band_first=first, band_stride=8, reset=(first == 0),
+                             collect_stats=False)
+        rays += c["camera_rays"]
+        rows = np.arange(H)
+        done = (rows // 16) % 8 <= first
+        assert banded[done].any() and not banded[~done].any()
+    assert rays == W * H * spp
+    _, total = gpu_ctx.read_accum()
+    assert total == spp
+    assert np.allclose(banded, one, rtol=2e-5, atol=1e-6)
+    # one band of the frame against the oracle (through the mesh, the walls and the floor)
+    y0, y1 = 1072, 1088
+    ref, cref = big_oracle.render(spp, BOUNCES, seed=71, rows=(y0, y1))
+    ref2, _ = big_oracle.render(spp, BOUNCES, seed=72, rows=(y0, y1))
+    st = parity.image_stats(ref[y0:y1], one[y0:y1])
+    noise = parity.image_stats(ref[y0:y1], ref2[y0:y1])
+    print(st, "noise rmse", noise["rmse"])
+    assert st["mean_rel"] <= 0.01 and st["rmse"] <= 1.5 * noise["rmse"] and st["frac_diff"] <= 0.06, (st, noise)

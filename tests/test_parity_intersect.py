@@ -21,7 +21,7 @@ def _f32_rays(rays):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("scene_name,n", [("cornell", 60000), ("mesh", 30000), ("glass", 30000)])
+@pytest.mark.parametrize("scene_name,n", [("cornell", 60000), ("mesh", 30000), ("glass", 30000), ("mirror_tex", 30000)])
 def test_random_rays_ids_exact(backend, scene_name, n, request):
     sd = scene(scene_name)
     o = _oracle(sd)
@@ -37,9 +37,16 @@ def test_random_rays_ids_exact(backend, scene_name, n, request):
     assert c["max_rel_t"] <= 1e-5, c
     rec = parity.check_hit_records(ref, got)
     print(rec)
-    assert rec["point"] < 1e-5 and rec["uv"] < 1e-4 and rec["material_mismatch"] == 0
+    # Sphere::texcoord goes through acos / atan2 of the unit hit vector: near the poles the fp32 error of the
+    # polar angle grows like 1 / sin(theta), so textured spheres get a wider bar than interpolated triangle uvs
+    assert rec["point"] < 1e-5 and rec["uv"] < (2e-3 if scene_name == "mirror_tex" else 1e-4) and rec["material_mismatch"] == 0
     assert rec["normal"] < 1e-5
     assert rec["inside_mismatch"] <= 1e-4 * rec["n"]
+    if scene_name == "mirror_tex":  # the textured sphere is hit, and its texture coordinates span the map
+        on_globe = (got["hit"] == 1) & (got["id"] == sd.n_triangles)
+        assert on_globe.sum() > 500
+        uv = got["uv"][on_globe]
+        assert uv.min() >= 0.0 and uv.max() <= 1.0 and np.ptp(uv[:, 0]) > 0.9 and np.ptp(uv[:, 1]) > 0.8
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

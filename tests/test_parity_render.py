@@ -27,6 +27,8 @@ CASES = [
     ("envmap", 24, 3),           # environment map + textured floor + depth of field
     ("sky", 24, 4),              # sky gradient, fuzzy specular, microfacet, sphere light
     ("tiled", 16, 3),            # floor texture coordinates in [-1, 2]
+    ("mirror_tex", 24, 5),       # textured sphere, MIRROR-type sphere and wall
+    ("envmap_full", 16, 3),      # environment map of 3584 x 1792 texels
 ]
 
 

@@ -199,6 +199,15 @@ int ptk_reset_accum(ptk_ctx* ctx);
  * (rows, bands, sample batches) only changes the fp32 order in which a pixel's samples are summed.
  * May allocate device memory the first time an image size is rendered. */
 int ptk_render(ptk_ctx* ctx, const ptk_render_params* params);
+/* -- ptk_render for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same
+ * launches and bit-identical sums, but the per-chunk partial sums of the frame live in a static 128 MiB
+ * device array instead of a buffer grown on demand, and no timing events are recorded (ptk_stats'
+ * kernel_ms_* do not include these launches).  Calls no hipMalloc / hipFree.  A call whose partial sums
+ * (16 bytes x pixels rendered x sample chunks, at most 32) exceed the array fails with PTK_ERR_LIMIT and a
+ * message that says so: render fewer rows or samples per call.  All calls on one GPU share that GPU's array:
+ * calls of different contexts that overlap in time on one GPU race; calls on one context are ordered by its stream. */
+int ptk_render_static(ptk_ctx* ctx, const ptk_render_params* params);
 /* -- the buffer Renderer::save_image reads (src/renderer.cpp:186): per-pixel mean radiance,
  * row 0 = top, W*H*3 floats, host memory.  Blocks until rendering has finished.
  * total_samples (may be NULL) receives the largest per-pixel sample count. */

@@ -59,6 +59,13 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 #define PTK_CHUNK_MIN_SAMPLES 16  // ... but never below this many samples per chunk
 #endif
 constexpr int kMaxChunks = 32;
+
+// Device memory of ptk_render_static, the render entry point that allocates nothing: the per-chunk partial sums
+// of a frame go here instead of into a buffer that grows on demand.  One copy per GPU, at its own address
+// (ptk_create asks the runtime for it with hipGetSymbolAddress: in host code the name `scratch` is not a
+// device address).  Every call on a GPU shares that GPU's copy.
+constexpr size_t kStaticScratchBytes = (size_t)128 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters of a PTK_PHASE_STATS build
 
 // A build with -DPTK_PHASE_STATS makes instrumented launches also count, per wave, how often each
@@ -464,6 +471,7 @@ struct ptk_ctx {
   size_t display_capacity = 0;   // in pixels
   f4* d_partial = nullptr;  // per-chunk partial sums of the frame being rendered
   size_t partial_capacity = 0;  // in f4
+  f4* d_static_scratch = nullptr;  // this device's copy of `scratch` (ptk_render_static)
   // counters and timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -573,6 +581,8 @@ int ptk_create(int device, ptk_ctx** out)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, kCounterSlots * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream);
+  // with `device` current: the address of this device's copy of the static scratch array
+  if (e == hipSuccess) e = hipGetSymbolAddress((void**)&ctx->d_static_scratch, HIP_SYMBOL(scratch));
   if (e != hipSuccess) {
     g_create_error = std::string("ptk_create: ") + hipGetErrorString(e);
     delete ctx;
@@ -754,7 +764,9 @@ int ptk_reset_accum(ptk_ctx* ctx)
   return PTK_OK;
 }
 
-int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
+// Body of ptk_render and ptk_render_static.  static_scratch: take the partial-sum buffer from the device's
+// static array, record no timing events and call nothing that allocates.
+static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_scratch)
 {
   if (!ctx) return PTK_ERR_INVALID;
   if (!p) return fail(ctx, PTK_ERR_INVALID, "ptk_render: params is NULL");
@@ -792,7 +804,15 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
   ra.chunks = pick_chunks(ra.n_tiles, p->samples);
   PTK_HIP(hipSetDevice(ctx->device));
   size_t band_pixels = (size_t)ra.rows * (size_t)ctx->cam.width;
-  if (ra.chunks > 1) {
+  f4* partial = ctx->d_partial;
+  if (static_scratch) {
+    partial = ctx->d_static_scratch;
+    const size_t need = ra.chunks > 1 ? band_pixels * (size_t)ra.chunks : 0;
+    if (need * sizeof(f4) > kStaticScratchBytes)
+      return fail(ctx, PTK_ERR_LIMIT, "ptk_render_static: " + std::to_string(band_pixels) + " pixels in " + std::to_string(ra.chunks) +
+                                          " sample chunks need " + std::to_string(need * sizeof(f4)) + " bytes of partial sums, the static buffer holds " +
+                                          std::to_string(kStaticScratchBytes) + ": render fewer rows (row_begin / row_end) or fewer samples per call");
+  } else if (ra.chunks > 1) {
     size_t need = band_pixels * (size_t)ra.chunks;
     if (need > ctx->partial_capacity) {
       PTK_HIP(hipStreamSynchronize(ctx->stream));  // an earlier frame may still be folding the old buffer
@@ -802,27 +822,33 @@ int ptk_render(ptk_ctx* ctx, const ptk_render_params* p)
       PTK_HIP(hipMalloc((void**)&ctx->d_partial, need * sizeof(f4)));
       ctx->partial_capacity = need;
     }
+    partial = ctx->d_partial;
   }
   std::pair<hipEvent_t, hipEvent_t> ev;
-  int rc = begin_timed(ctx, ev);
+  int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
   if (p->collect_stats)
     hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
-                       ctx->d_partial, ctx->d_counters);
+                       partial, ctx->d_counters);
   else
     hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
-                       ctx->d_partial, ctx->d_counters);
+                       partial, ctx->d_counters);
   PTK_HIP(hipGetLastError());
-  rc = end_timed(ctx, ev);
+  if (static_scratch) ctx->launches++;
+  else rc = end_timed(ctx, ev);
   if (rc) return rc;
   if (ra.chunks > 1) {
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)((band_pixels + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum,
-                       ctx->d_partial, ra, ctx->cam.width);
+                       partial, ra, ctx->cam.width);
     PTK_HIP(hipGetLastError());
   }
   return PTK_OK;
 }
+
+int ptk_render(ptk_ctx* ctx, const ptk_render_params* p) { return render_common(ctx, p, false); }
+
+int ptk_render_static(ptk_ctx* ctx, const ptk_render_params* p) { return render_common(ctx, p, true); }
 
 int ptk_synchronize(ptk_ctx* ctx)
 {

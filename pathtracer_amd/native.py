@@ -88,7 +88,7 @@ assert HIT_DTYPE.itemsize == 52
 
 # every symbol include/ptk.h declares
 EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "ptk_upload_scene_ex", "ptk_scene_info_get", "ptk_set_camera",
-           "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_read_accum", "ptk_read_display_u8", "ptk_synchronize",
+           "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_render_static", "ptk_read_accum", "ptk_read_display_u8", "ptk_synchronize",
            "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream"]
 
 
@@ -184,6 +184,7 @@ def load_library():
     L.ptk_bind_accum.argtypes = [vp, vp]
     L.ptk_reset_accum.argtypes = [vp]
     L.ptk_render.argtypes = [vp, C.POINTER(PtkRenderParams)]
+    L.ptk_render_static.argtypes = [vp, C.POINTER(PtkRenderParams)]
     L.ptk_read_accum.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.ptk_read_display_u8.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.ptk_synchronize.argtypes = [vp]
@@ -253,11 +254,15 @@ class Context:
         self._check(self._L.ptk_reset_accum(self.h), "ptk_reset_accum")
 
     def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, row_begin=0, row_end=0,
-               collect_stats=False, band_rows=0, band_first=0, band_stride=1):
+               collect_stats=False, band_rows=0, band_first=0, band_stride=1, static=False):
+        """static=True: ptk_render_static, the variant that allocates no device memory."""
         p = PtkRenderParams(int(samples), int(max_bounce), int(seed), int(sample_first), int(sample_stride),
                             int(row_begin), int(row_end), 1 if collect_stats else 0, int(band_rows), int(band_first),
                             int(band_stride))
-        self._check(self._L.ptk_render(self.h, C.byref(p)), "ptk_render")
+        if static:
+            self._check(self._L.ptk_render_static(self.h, C.byref(p)), "ptk_render_static")
+        else:
+            self._check(self._L.ptk_render(self.h, C.byref(p)), "ptk_render")
 
     def synchronize(self):
         self._check(self._L.ptk_synchronize(self.h), "ptk_synchronize")

@@ -1,15 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the render path: Mrays/s and ms/frame.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload all|bunny|cornell|bmw|envmap|glass]
 
 A step is one frame: Renderer::render(spp) over the whole image (src/renderer.cpp:27-52), i.e. one pass of
 the path kernel, with the scene already resident in HBM.  A ray is one closest-hit query
 (Scene::find_intersection, src/scene.cpp:19): a path segment or a shadow ray that is actually traced; the
-count comes from the kernel's own counters.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) every GPU renders `spp` samples of the frame with interleaved global sample indices
-(weak scaling: the frame gets N x spp samples; --split tile shares one frame's rows instead) and the
-accumulation buffers are summed onto rank 0 with one RCCL reduce per frame, inside the timed region.
+count comes from the kernel's own counters.
+
+The top-level numbers are the `bunny` workload (Cornell box + 81,920-triangle mesh, 1024 x 1024, 1024 spp:
+the configuration the metric names for one GPU).  With the default `--workload all` on one GPU the Cornell box
+and the 1.3 M-triangle scene (the two scenes the metric is quoted on) are measured in the same run and
+reported under "extra", each with its own roofline and CPU baseline.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (children under
+torch.distributed.run, before this process touches a GPU); under torch.distributed.run it is a rank.  Every GPU
+renders `spp` samples of the frame with interleaved global sample indices (weak scaling: the frame gets
+N x spp samples; --split tile shares one frame's rows instead) and the accumulation buffers are merged onto
+rank 0 with one RCCL collective per frame, inside the timed region.
+
+Roofline: nothing here is a dense contraction and the scenes are cache resident, so the bound that applies
+is the fp32 vector rate: algorithmic flops per ray (21 per box test, 60 per primitive test, 250 per shaded
+segment; tests per ray counted by an instrumented launch on the same scene) x rays per launch / the kernel's
+launch time from HIP events on its own stream, against 157.3 TFLOP/s.  The same accounting in bytes (32 per
+box test, 36 per primitive test, 48 per ray) is reported as "algorithmic_gbs": it exceeds the HBM peak because
+those bytes come from L1 / L2, which is why HBM is not the bound; "traffic" is the HBM-side byte count per
+launch measured with the hardware counters (profiles/traffic.json), "hbm_frac" that traffic over the launch
+time against 8 TB/s.  "frac" is the larger of the two fractions.
 
 Prints ONE JSON line on rank 0.
 """
@@ -18,6 +35,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,18 +44,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 WORKLOADS = {
-    # name: (description, builder kwargs)
     "bunny": "Cornell box + 81,920-triangle smooth mesh (bunny-class stand-in: diffuse + emissive area light)",
     "cornell": "Cornell box OBJ (12 triangles, textured floor, depth of field)",
     "bmw": "Cornell box + 1,310,720-triangle mesh (BMW-class stand-in)",
     "envmap": "Cornell box (textured floor) + 81,920-triangle mesh, 3584x1792 environment map, depth of field",
     "glass": "Cornell box + dielectric 20,480-triangle mesh + glass and mirror spheres (Russian roulette active)",
 }
-# per-workload defaults for (width, height, spp, bounces) where they differ from the command line's
+# per-workload defaults for (width, height, spp, bounces)
 WORKLOAD_DEFAULTS = {"envmap": (1920, 1080, 1024, 3), "glass": (500, 500, 2048, 8)}
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 
 
 def build_scene(name, width, height):
@@ -54,82 +72,85 @@ def build_scene(name, width, height):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(sd, budget_s=15.0):
+def cpu_baseline(sd, spp_max, bounces, budget_s):
     """The CPU oracle (a restatement of the reference renderer) timed on this box's host cores on a bounded
     sample of the same workload: a band of rows in the middle of the frame, sized from a one-sample probe so
-    that the timed run takes about budget_s seconds."""
+    that the timed run takes about budget_s seconds.  Also its single-thread rate on a smaller band, to set
+    beside the reference's own single-thread rate (0.908 M trace_ray bodies per second on the Cornell box)."""
     from oracle import orc
     o = orc.OracleScene(sd)
     h = sd.camera.height
     threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
-    band = max(8, min(h, 64))
+    band = probe_band = max(8, min(h, 64))
     y0 = (h - band) // 2
     t = time.perf_counter()
-    o.render(1, ARGS.bounces, seed=99, rows=(y0, y0 + band), threads=threads)
+    o.render(1, bounces, seed=99, rows=(y0, y0 + band), threads=threads)
     t1 = max(time.perf_counter() - t, 1e-4)  # one sample per pixel of the probe band
-    spp = int(max(1, min(ARGS.spp, budget_s / t1)))
-    if spp == ARGS.spp:  # the band at full spp is still short: widen it
+    spp = int(max(1, min(spp_max, budget_s / t1)))
+    if spp == spp_max:  # the band at full spp is still short: widen it
         band = int(max(band, min(h, band * budget_s / (t1 * spp))))
         y0 = (h - band) // 2
     t = time.perf_counter()
-    _, c = o.render(spp, ARGS.bounces, seed=100, rows=(y0, y0 + band), threads=threads)
+    _, c = o.render(spp, bounces, seed=100, rows=(y0, y0 + band), threads=threads)
     dt = time.perf_counter() - t
+    # one thread on eight rows, about a seventh of the budget (t1 was `threads` threads on probe_band rows)
+    spp1 = int(max(1, min(spp_max, budget_s * 0.15 / (t1 * threads * 8.0 / probe_band))))
+    y1 = (h - 8) // 2
+    t = time.perf_counter()
+    _, c1 = o.render(spp1, bounces, seed=101, rows=(y1, y1 + 8), threads=1)
+    dt1 = max(time.perf_counter() - t, 1e-6)
     return {"value": c["queries"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"rows {y0}..{y0 + band} of the frame, {spp} spp, {ARGS.bounces} bounces, "
+            "sample": f"rows {y0}..{y0 + band} of the frame, {spp} spp, {bounces} bounces, "
                       f"{c['queries']} rays in {dt:.2f} s",
             "segments_per_s": c["segments"] / dt, "prim_tests_per_ray": c["prim_tests"] / max(1, c["queries"]),
-            "box_tests_per_ray": c["box_tests"] / max(1, c["queries"])}
+            "box_tests_per_ray": c["box_tests"] / max(1, c["queries"]),
+            "single_thread": {"segments_per_s": c1["segments"] / dt1, "rays_per_s": c1["queries"] / dt1,
+                              "sample": f"rows {y1}..{y1 + 8}, {spp1} spp, {dt1:.2f} s",
+                              "reference_single_thread_segments_per_s_cornell": 0.908e6}}
 
 
-def main():
-    import torch
-    import torch.distributed as dist
-    from pathtracer_amd import native, parallel
+def traffic_entry(key):
+    """HBM-side bytes per launch of exactly this configuration from the hardware-counter passes whose summary is
+    committed under profiles/ (tools/profile.sh + tools/make_traffic.py); None when it was not profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != ARGS.gpus:
-        if world == 1 and ARGS.gpus > 1:
-            raise SystemExit("--gpus N > 1 needs one process per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the render path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    sd = build_scene(ARGS.workload, ARGS.width, ARGS.height)
-    ctx = native.Context(local_rank)
-    ctx.upload_scene(sd, ARGS.builder)
+def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
+    """Times `args.steps` frames of one workload; returns the result dictionary (rank 0) or None."""
+    from pathtracer_amd import parallel
+    width, height, spp, bounces = args.sizes[name]
+    sd = build_scene(name, width, height)
+    ctx.upload_scene(sd, args.builder)
     ctx.set_camera(sd.camera)
     info = ctx.scene_info()
-    accum = torch.zeros((ARGS.height, ARGS.width, 4), dtype=torch.float32, device=dev)
+    accum = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     ctx.bind_accum(accum.data_ptr())
-
-    plan = parallel.frame_plan(ARGS.split, rank, world, ARGS.spp, ARGS.height, batch=ARGS.batch)
+    plan = parallel.frame_plan(args.split, rank, world, spp, height, batch=args.batch)
+    merge = parallel.FrameMerge(args.split, rank, world, accum)
 
     def frame(step):
         accum.zero_()
         torch.cuda.synchronize()  # the kernel runs on the library's own stream
         for c in plan:
-            ctx.render(c.samples, ARGS.bounces, seed=ARGS.seed + step, sample_first=c.sample_first,
+            ctx.render(c.samples, bounces, seed=args.seed + step, sample_first=c.sample_first,
                        sample_stride=c.sample_stride, row_begin=c.row_begin, row_end=c.row_end,
                        band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
         ctx.synchronize()
-        parallel.reduce_frame(accum, world)  # RCCL over xGMI: the frame's one exchange step
+        merge.run()  # RCCL over xGMI: the frame's one exchange step
 
-    for w in range(ARGS.warmup):
+    for w in range(args.warmup):
         frame(-1 - w)
     ctx.reset_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(ARGS.steps):
+    for s in range(args.steps):
         frame(s)
     if world > 1:
         dist.barrier()
@@ -145,64 +166,95 @@ def main():
     elapsed = float(tt.item())
     queries, segments, camera_rays = [float(x) for x in counts.tolist()]
 
-    # instrumented pass on the same scene: box / primitive tests per ray for the algorithmic-work figure
+    # instrumented pass on the same scene: box / primitive tests per ray for the algorithmic-work figures
     ctx.reset_stats()
     accum.zero_()
     torch.cuda.synchronize()
-    ctx.render(max(1, min(ARGS.stats_spp, ARGS.spp)), ARGS.bounces, seed=7, collect_stats=True)
+    ctx.render(max(1, min(args.stats_spp, spp)), bounces, seed=7, collect_stats=True)
     si = ctx.stats()
+    ctx.bind_accum(None)
     box_per_ray = si["box_tests"] / max(1, si["queries"])
     prim_per_ray = si["prim_tests"] / max(1, si["queries"])
     seg_per_ray = si["segments"] / max(1, si["queries"])
+    if rank != 0:
+        return None
 
+    bytes_per_ray = box_per_ray * 32.0 + prim_per_ray * 36.0 + 48.0
+    flops_per_ray = box_per_ray * 21.0 + prim_per_ray * 60.0 + 250.0 * seg_per_ray
+    rays_per_launch = st["queries"] / max(1, st["launches"])
+    kernel_s = (st["kernel_ms_total"] / max(1, st["launches"])) / 1e3
+    achieved_tf = rays_per_launch * flops_per_ray / kernel_s / 1e12
+    algorithmic_gbs = rays_per_launch * bytes_per_ray / kernel_s / 1e9
+    tr = traffic_entry(f"{name}_{width}x{height}_{spp}spp")
+    traffic = tr.get("hbm_bytes_per_launch") if tr else None
+    valu_frac = achieved_tf / PEAK_FP32_TFLOPS
+    hbm_frac = (traffic / kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None
+    roofline = {"bound": "fp32_valu", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac,
+                "traffic": traffic, "hbm_frac": hbm_frac, "kernel": "render_kernel", "kernel_ms_avg": kernel_s * 1e3,
+                "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray, "box_tests_per_ray": box_per_ray,
+                "prim_tests_per_ray": prim_per_ray, "rays_per_launch": rays_per_launch,
+                "algorithmic_gbs": algorithmic_gbs, "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
+                "l2_hit_rate": tr.get("l2_hit_rate") if tr else None,
+                "valu_lane_utilisation": tr.get("valu_lane_utilisation") if tr else None,
+                "valu_issue_slots_used": tr.get("valu_issue_slots_used") if tr else None,
+                "wait_fraction": tr.get("wait_fraction") if tr else None,
+                "note": "scene is cache resident: algorithmic bytes are served by L1/L2, HBM traffic is a few percent of "
+                        "its peak, so the fp32 vector rate is the bound reported; counters from profiles/"}
+    if hbm_frac is not None and hbm_frac > valu_frac:
+        roofline.update({"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac})
+    out = {
+        "value": queries / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / args.steps * 1e3,
+        "config": {"workload": f"{name}: {WORKLOADS[name]}; {width}x{height}, {spp} spp per GPU, {bounces} bounces",
+                   "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"],
+                   "bvh_builder": "device" if info["builder"] else "host",
+                   "scene_upload_ms": round(info["upload_ms"], 2), "device_build_ms": round(info["device_build_ms"], 3),
+                   "split": (f"{args.split} split, {merge.describe()}" if world > 1 else "none"),
+                   "launches_per_frame": st["launches"] // max(1, args.steps)},
+        "ms_per_frame": elapsed / args.steps * 1e3,
+        "segments_per_s": segments / elapsed, "paths_per_s": camera_rays / elapsed,
+        "rays_per_segment": queries / max(1.0, segments),
+        "roofline": roofline,
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(sd, spp, bounces, args.cpu_seconds)
+    return out
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})", file=sys.stderr, flush=True)
+
+    names = ["bunny", "cornell", "bmw"] if args.workload == "all" else [args.workload]
+    if world > 1 and args.workload == "all":
+        names = ["bunny"]  # the scaling runs time the headline workload only
+    ctx = native.Context(local_rank)
+    results = {}
+    for name in names:
+        results[name] = run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu=(world == 1 and not args.no_cpu))
     if rank == 0:
-        # algorithmic bytes per ray: 32 B per child box tested (6 fp32 bounds + 2 links), 36 B per primitive
-        # tested (3 fp32 positions x 3), 32 B ray in, 16 B hit out
-        bytes_per_ray = box_per_ray * 32.0 + prim_per_ray * 36.0 + 48.0
-        flops_per_ray = box_per_ray * 21.0 + prim_per_ray * 60.0 + 250.0 * seg_per_ray
-        rays_per_launch = st["queries"] / max(1, st["launches"])
-        kernel_s = (st["kernel_ms_total"] / max(1, st["launches"])) / 1e3
-        achieved_gbs = rays_per_launch * bytes_per_ray / kernel_s / 1e9
-        achieved_tf = rays_per_launch * flops_per_ray / kernel_s / 1e12
-        # memory-side bytes per launch of this exact configuration, from the hardware-counter passes whose
-        # summary is committed under profiles/ (tools/profile.sh + tools/make_traffic.py); null for others
-        traffic, l2_hit = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"{ARGS.workload}_{ARGS.width}x{ARGS.height}_{ARGS.spp}spp"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-                l2_hit = tj.get(key, {}).get("l2_hit_rate")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mrays/s", "value": queries / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
-            "steps": ARGS.steps, "warmup": ARGS.warmup, "ms_per_step": elapsed / ARGS.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if ARGS.split == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ARGS.workload}: {WORKLOADS[ARGS.workload]}; {ARGS.width}x{ARGS.height}, "
-                                   f"{ARGS.spp} spp per GPU, {ARGS.bounces} bounces",
-                       "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"], "bvh_builder": "device" if info["builder"] else "host",
-                       "scene_upload_ms": round(info["upload_ms"], 2), "device_build_ms": round(info["device_build_ms"], 3),
-                       "split": (f"{ARGS.split} split, one RCCL reduce per frame" if world > 1 else "none"),
-                       "launches_per_frame": st["launches"] // max(1, ARGS.steps)},
-            "ms_per_frame": elapsed / ARGS.steps * 1e3,
-            "segments_per_s": segments / elapsed, "paths_per_s": camera_rays / elapsed,
-            "rays_per_segment": queries / max(1.0, segments),
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved_gbs / 8000.0, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray, "l2_hit_rate": l2_hit,
-                         "note": "achieved counts every box and primitive test as bytes fetched; the scene is "
-                                 "cache resident (traffic << algorithmic bytes), so frac can exceed 1; the "
-                                 "kernel is bound by load latency and L1 accesses per ray, not by HBM: see fp32_valu and profiles/",
-                         "kernel": "render_kernel", "kernel_ms_avg": kernel_s * 1e3,
-                         "bytes_per_ray": bytes_per_ray, "box_tests_per_ray": box_per_ray,
-                         "prim_tests_per_ray": prim_per_ray, "rays_per_launch": rays_per_launch,
-                         "fp32_valu": {"achieved": achieved_tf, "peak": 157.3, "unit": "TFLOP/s",
-                                       "frac": achieved_tf / 157.3, "flops_per_ray": flops_per_ray}},
-        }
-        if world == 1 and not ARGS.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(sd)
+        head = results[names[0]]
+        out = {"metric": "Mrays/s", "value": head["value"], "unit": "Mrays/s",
+               "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak" if args.split == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        out.update({k: v for k, v in head.items() if k not in ("value", "unit", "ms_per_step")})
+        if len(names) > 1:
+            out["extra"] = {n: results[n] for n in names[1:]}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
@@ -210,12 +262,27 @@ def main():
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks as children of a fresh launcher
+    process (nothing in this process has touched a GPU), pass their output through, return their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="all", choices=["all"] + sorted(WORKLOADS),
+                    help="all = bunny (the top-level numbers) + cornell + bmw under 'extra'")
     ap.add_argument("--width", type=int, default=None, help="default 1024 (workloads envmap and glass have their own)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per GPU, default 1024")
@@ -228,10 +295,17 @@ if __name__ == "__main__":
     ap.add_argument("--builder", default=None, choices=["host", "device"],
                     help="tree builder (default: host surface-area-heuristic build; device: linear BVH built on the GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ARGS = ap.parse_args()
-    _w, _h, _s, _b = WORKLOAD_DEFAULTS.get(ARGS.workload, (1024, 1024, 1024, 3))
-    ARGS.width = ARGS.width or _w
-    ARGS.height = ARGS.height or _h
-    ARGS.spp = ARGS.spp or _s
-    ARGS.bounces = ARGS.bounces if ARGS.bounces is not None else _b
-    main()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget of each workload's baseline leg")
+    args = ap.parse_args(argv)
+    args.sizes = {}
+    for name in WORKLOADS:
+        w, h, s, b = WORKLOAD_DEFAULTS.get(name, (1024, 1024, 1024, 3))
+        args.sizes[name] = (args.width or w, args.height or h, args.spp or s, args.bounces if args.bounces is not None else b)
+    return args
+
+
+if __name__ == "__main__":
+    ARGS = parse_args()
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(ARGS))
+    main(ARGS)

@@ -12,8 +12,10 @@ single GPU would render:
   "tile"  rank r renders all samples of the 16-row bands b with b % world == r (interleaved for balance),
           all of them in one launch per batch.
 
-The accumulation buffer holds (sum r, sum g, sum b, sample count) per pixel, so a SUM reduce merges either
-kind of shard: disjoint bands add zeros, interleaved samples add partial sums and counts.
+The accumulation buffer holds (sum r, sum g, sum b, sample count) per pixel.  Interleaved samples are merged
+by a SUM reduce of the whole buffer onto rank 0 (W*H*16 bytes per rank).  Disjoint bands need no arithmetic:
+each rank sends only its own bands, packed, and rank 0 puts them in place (a gather of W*H*16/world bytes per
+rank).
 """
 from __future__ import annotations
 
@@ -79,3 +81,51 @@ def reduce_frame(accum, world: int, dst: int = 0):
         import torch.distributed as dist
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
+
+
+class FrameMerge:
+    """The frame's one exchange step, set up once per image size.
+
+    spp split: dist.reduce(SUM) of the whole buffer.  tile split: every rank packs the rows of its own bands
+    into a contiguous tensor (padded to the largest share), one dist.gather brings the shares to rank `dst`,
+    which copies them into its buffer; 1/world of the buffer moves per rank instead of all of it."""
+
+    def __init__(self, split: str, rank: int, world: int, accum, dst: int = 0):
+        self.split, self.rank, self.world, self.accum, self.dst = split, rank, world, accum, dst
+        self.rows = None
+        if world > 1 and split == "tile":
+            import torch
+            height = accum.shape[0]
+            shares = [RenderCall(0, 0, 1, 0, 0, BAND_ROWS, r, world).rows(height) for r in range(world)]
+            self.most = max(len(s) for s in shares)
+            self.rows = [torch.as_tensor(list(s), dtype=torch.long, device=accum.device) for s in shares]
+            self.send = torch.zeros((self.most,) + tuple(accum.shape[1:]), dtype=accum.dtype, device=accum.device)
+            self.recv = ([torch.zeros_like(self.send) for _ in range(world)] if rank == dst else None)
+
+    def bytes_per_rank(self) -> int:
+        if self.world <= 1:
+            return 0
+        t = self.send if self.rows is not None else self.accum
+        return t.numel() * t.element_size()
+
+    def describe(self) -> str:
+        if self.rows is not None:
+            return f"one RCCL gather of each rank's own bands per frame ({self.bytes_per_rank()} bytes per rank)"
+        return f"one RCCL sum-reduce of the accumulation buffer per frame ({self.bytes_per_rank()} bytes per rank)"
+
+    def run(self):
+        if self.world <= 1:
+            return self.accum
+        import torch.distributed as dist
+        if self.rows is None:
+            dist.reduce(self.accum, dst=self.dst, op=dist.ReduceOp.SUM)
+            return self.accum
+        mine = self.rows[self.rank]
+        if len(mine):
+            self.send[: len(mine)] = self.accum[mine]
+        dist.gather(self.send, self.recv, dst=self.dst)
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r != self.rank and len(self.rows[r]):
+                    self.accum[self.rows[r]] = self.recv[r][: len(self.rows[r])]
+        return self.accum

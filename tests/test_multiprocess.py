@@ -36,7 +36,9 @@ def _worker(rank, world, port, split, spp, bounces, out_path):
                  row_begin=c.row_begin, row_end=c.row_end, accum=accum,
                  band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
     t = torch.from_numpy(accum)
-    parallel.reduce_frame(t, world)
+    merge = parallel.FrameMerge(split, rank, world, t)
+    assert merge.bytes_per_rank() == (t.numel() * 4 if split == "spp" else 24 * 40 * 16)  # the largest share: bands 0 and 2 = rows 0..15 and 32..39
+    merge.run()
     if rank == 0:
         np.save(out_path, t.numpy())
     dist.barrier()
@@ -86,3 +88,79 @@ def test_frame_plan_covers_every_sample_once():
         parallel.frame_plan("rows", 0, 1, 4, 16)
     with pytest.raises(ValueError):
         parallel.frame_plan("spp", 2, 2, 4, 16)
+
+
+def _gpu_worker(rank, world, port, split, spp, bounces, out_path):
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import native
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sd = scenes.cornell_with_mesh(3, 96, 72)
+    ctx = native.Context(rank)
+    ctx.upload_scene(sd)
+    ctx.set_camera(sd.camera)
+    accum = torch.zeros((72, 96, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.bind_accum(accum.data_ptr())
+    merge = parallel.FrameMerge(split, rank, world, accum)
+    for c in parallel.frame_plan(split, rank, world, spp, 72, batch=16):
+        ctx.render(c.samples, bounces, seed=4, sample_first=c.sample_first, sample_stride=c.sample_stride,
+                   row_begin=c.row_begin, row_end=c.row_end, band_rows=c.band_rows, band_first=c.band_first,
+                   band_stride=c.band_stride)
+    ctx.synchronize()  # the library renders on its own stream; the collective runs on torch's
+    merge.run()
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(out_path, accum.cpu().numpy())
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("split", ["tile", "spp"])
+def test_two_gpus_reproduce_the_single_gpu_frame(split, tmp_path):
+    """The real N > 1 sequence: libptk renders into a torch tensor bound as the accumulation buffer on each
+    GPU, then one RCCL collective merges the frame on rank 0.  Tile split: bit-identical to one GPU rendering
+    the same bands; spp split: equal up to fp32 summation order."""
+    import torch.multiprocessing as mp
+    from pathtracer_amd import native
+    world, spp, bounces = 2, 32, 3
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_gpu_worker, args=(world, _free_port(), split, spp, bounces, out), nprocs=world, join=True)
+    merged = np.load(out)
+    sd = scenes.cornell_with_mesh(3, 96, 72)
+    ctx = native.Context(0)
+    try:
+        ctx.upload_scene(sd)
+        ctx.set_camera(sd.camera)
+        total = spp if split == "tile" else spp * world
+        if split == "tile":
+            for r in range(world):
+                for c in parallel.frame_plan("tile", r, world, spp, 72, batch=16):
+                    ctx.render(c.samples, bounces, seed=4, sample_first=c.sample_first, sample_stride=c.sample_stride,
+                               band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
+        else:
+            ctx.render(total, bounces, seed=4)
+        single, n = ctx.read_accum()
+    finally:
+        ctx.close()
+    assert n == total and (merged[..., 3] == total).all()
+    mean = merged[..., :3] / merged[..., 3:4]
+    if split == "tile":
+        assert np.array_equal(mean, single)
+    assert np.allclose(mean, single, rtol=2e-5, atol=1e-5)

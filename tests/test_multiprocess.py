@@ -160,7 +160,7 @@ def test_two_gpus_reproduce_the_single_gpu_frame(split, tmp_path):
     finally:
         ctx.close()
     assert n == total and (merged[..., 3] == total).all()
-    mean = merged[..., :3] / merged[..., 3:4]
+    mean = merged[..., :3] * (np.float32(1.0) / merged[..., 3:4])  # as ptk_read_accum forms it: fp32 reciprocal, fp32 product
     if split == "tile":
         assert np.array_equal(mean, single)
     assert np.allclose(mean, single, rtol=2e-5, atol=1e-5)

@@ -219,9 +219,11 @@ int ptk_read_display_u8(ptk_ctx* ctx, uint8_t* rgb8, int32_t* total_samples);
 int ptk_synchronize(ptk_ctx* ctx);
 
 /* -- Scene::find_intersection (src/scene.cpp:19) over a batch of rays.
- * Host arrays; blocks. */
+ * Host arrays; blocks.  The device staging buffers are kept between calls: a batch no larger than an
+ * earlier one (a single ray, say) allocates nothing. */
 int ptk_intersect_batch(ptk_ctx* ctx, const ptk_ray* rays, int32_t n, ptk_hit* hits);
-/* Same with device-resident inputs/outputs: rays as n*6 floats (origin, direction); asynchronous. */
+/* Same with device-resident inputs/outputs: rays as n*6 floats (origin, direction; the array 8-byte
+ * aligned); asynchronous. */
 int ptk_intersect_batch_device(ptk_ctx* ctx, const float* device_rays, int32_t n, ptk_hit* device_hits);
 
 /* -- counters: print_stats (src/geometry.cpp:273-278) */

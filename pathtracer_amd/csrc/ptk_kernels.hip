@@ -66,7 +66,7 @@ constexpr int kMaxChunks = 32;
 // device address).  Every call on a GPU shares that GPU's copy.
 constexpr size_t kStaticScratchBytes = (size_t)128 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
-constexpr int kCounterSlots = 16;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters of a PTK_PHASE_STATS build
+constexpr int kCounterSlots = 24;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters and 16-20 phase clocks of a PTK_PHASE_STATS build
 
 // A build with -DPTK_PHASE_STATS makes instrumented launches also count, per wave, how often each
 // phase of the render loop ran and how many lanes it ran for (printed by ptk_get_stats when the
@@ -253,6 +253,9 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   //   refill   - lanes whose path has ended take the tile's next work items.
   // Lanes not in the running phase keep their state (node in a register, stack in LDS).
   PTK_PHASE(uint32_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};)
+  // clock cycles the wave spends in each phase (s_memtime; the stamps themselves cost about a tenth of the run)
+  PTK_PHASE(unsigned long long tph[5] = {0, 0, 0, 0, 0}; unsigned long long tmark = __builtin_amdgcn_s_memtime();)
+#define PTK_PHASE_CLOCK(k) PTK_PHASE({ unsigned long long tnow = __builtin_amdgcn_s_memtime(); tph[k] += tnow - tmark; tmark = tnow; })
   bool need = false;  // this lane's path has ended and it has not been given a new work item yet
   int32_t held = kTravDone;  // a leaf the lane has reached but not intersected yet (kTravDone: none)
   for (;;) {
@@ -270,12 +273,14 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
     }
+    PTK_PHASE_CLOCK(0)
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
     if (held != kTravDone) {
       if (trav_leaf_prims<STATS>(ps.tr, held, sc, cnt)) ps.tr.node = kTravDone;
       held = kTravDone;
     }
     if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    PTK_PHASE_CLOCK(1)
     const bool done = trav_done(ps.tr);
     const bool waiting = ps.alive && done && !need;
     const bool lit = waiting && ps.shadow, shade = waiting && !ps.shadow;
@@ -285,17 +290,23 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
       if (lit && path_consume_shadow(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
     }
+    PTK_PHASE_CLOCK(2)
     if (n_shade >= PTK_SHADE_MIN || (idle && n_shade > 0)) {
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
       if (shade && path_shade(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
     }
+    PTK_PHASE_CLOCK(3)
     const int n_need = __popcll(__ballot(need));
     if (n_need >= PTK_ITEM_MIN || (idle && n_need > 0)) {
       refill(need);
       need = false;
     }
+    PTK_PHASE_CLOCK(4)
   }
-  PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);)
+  PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);
+    for (int k = 0; k < 5; k++) atomicAdd(&counters[16 + k], tph[k]);
+  })
   __syncthreads();
   const int px = pp.x0 + (lane & 7), py = pp.y0 + (lane >> 3);  // lane l writes out pixel slot l
   if (px < pp.x_end && py < pp.y_end) {
@@ -336,13 +347,24 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(f4* __restrict__ acc
   accum[o] = a;
 }
 
+// Experiment hooks of the ray-batch kernel: PTK_INTERSECT_WAVES=n asks the compiler for n waves per SIMD,
+// PTK_INTERSECT_LDS_PAD=bytes takes LDS away (fewer resident waves), PTK_EXP_NO_HIT_OUTPUT drops the result stores.
+#ifndef PTK_INTERSECT_WAVES
+#define PTK_INTERSECT_WAVES 1
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
+__global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
                                                            ptk_hit* __restrict__ hits, unsigned long long* counters)
 {
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  __shared__ uint32_t lds_finished[kBlock];  // the lanes whose records wait to be written out, in rank order
+#ifdef PTK_INTERSECT_LDS_PAD
+  __shared__ uint32_t lds_pad[PTK_INTERSECT_LDS_PAD / 4];
+  if (n < 0) lds_pad[threadIdx.x] = 1u;  // never true: keeps the array
+#endif
   LdsStack st;
   st.attach(lds_stack, (int)threadIdx.x);
+  const uint32_t lane = threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
   // A wave owns a contiguous run of the batch (the grid is capped by launch_intersect: a quarter of a million
   // one-shot workgroups, each ending in counter atomics, cost ten times the traversal) and works through it
@@ -354,9 +376,16 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
   Traversal tr;
   tr.node = kTravDone;
   tr.o = tr.d = V3(0.f, 0.f, 0.f);
-  long long mine = -1;  // the ray this lane is working on
+  int32_t mine = -1;  // the ray this lane is working on
   int32_t held = kTravDone;
   bool alive = true;
+  // Hit records leave through LDS.  A 52-byte record written by its own lane is thirteen 4-byte stores to
+  // sixty-four scattered places per wave; instead a finished lane puts its record into its own (now empty)
+  // stack region, and the whole wave then copies the finished records out with consecutive lanes writing
+  // consecutive words, so that a store instruction covers whole records.
+  constexpr uint32_t kRecordWords = sizeof(ptk_hit) / 4;
+  static_assert(sizeof(ptk_hit) % 4 == 0 && kRecordWords + 2 <= (uint32_t)kStackDepth && PTK_STACK_LANE_MAJOR,
+                "a hit record and its ray index must fit a lane's stack region above the sentinel");
   for (;;) {
     const bool done = trav_done(tr);
     const bool need = alive && done;
@@ -364,7 +393,9 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
     const bool idle = __ballot(!done) == 0ull;
     if (idle && need_mask == 0ull) break;
     if (__popcll(need_mask) >= PTK_ITEM_MIN || idle) {
-      if (need && mine >= 0) {
+      const bool finished = need && mine >= 0;
+      const unsigned long long fin_mask = __ballot(finished);
+      if (finished) {
         ptk_hit out;
         memset(&out, 0, sizeof out);
         if (tr.hit.id != kNoPrim) {
@@ -376,17 +407,40 @@ __global__ __launch_bounds__(kBlock) void intersect_kernel(SceneView sc, const f
           out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
           out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
         }
-        hits[mine] = out;
+        uint32_t* rec = st.base + 1;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&out);
+#pragma unroll
+        for (uint32_t k = 0; k < kRecordWords; k++) rec[k] = w[k];
+        rec[kRecordWords] = (uint32_t)mine;
+        const uint32_t frank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fin_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fin_mask, 0u));
+        lds_finished[frank] = lane;
+      }
+      if (fin_mask != 0ull) {  // wave-uniform
+        __syncthreads();  // one wave: orders the LDS writes above before the reads below
+        const uint32_t total = (uint32_t)__popcll(fin_mask) * kRecordWords;
+        uint32_t* out_words = reinterpret_cast<uint32_t*>(hits);
+        for (uint32_t i = lane; i < total; i += kBlock) {
+          const uint32_t r = i / kRecordWords, k = i - r * kRecordWords;
+          const uint32_t* rec = lds_stack + lds_finished[r] * (uint32_t)kStackDepth + 1;
+#ifndef PTK_EXP_NO_HIT_OUTPUT
+          out_words[(size_t)rec[kRecordWords] * kRecordWords + k] = rec[k];
+#else
+          if (rec[k] == 0xdeadbeefu) out_words[0] = 1u;
+#endif
+        }
+        __syncthreads();  // the stack regions are reused by the queries that start below
       }
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
       const long long take = next + rank;
       next += __popcll(need_mask);
       if (need) {
         if (take < end) {
-          const float* r = rays + 6 * (size_t)take;
-          mine = take;
+          // origin and direction as three 8-byte loads (a ray is 24 bytes, 8-byte aligned)
+          const float2* r = reinterpret_cast<const float2*>(rays) + 3 * (size_t)take;
+          const float2 a = r[0], b = r[1], c = r[2];
+          mine = (int32_t)take;
           cnt.queries++;
-          trav_begin(tr, st, sc, V3(r[0], r[1], r[2]), V3(r[3], r[4], r[5]), kTMax, kNoPrim);
+          trav_begin(tr, st, sc, V3(a.x, a.y, b.x), V3(b.y, c.x, c.y), kTMax, kNoPrim);
         } else {
           alive = false;
           mine = -1;
@@ -472,6 +526,11 @@ struct ptk_ctx {
   f4* d_partial = nullptr;  // per-chunk partial sums of the frame being rendered
   size_t partial_capacity = 0;  // in f4
   f4* d_static_scratch = nullptr;  // this device's copy of `scratch` (ptk_render_static)
+  // staging of ptk_intersect_batch's host arrays; kept between calls, so that a batch no larger than an earlier
+  // one (a single ray of Scene::find_intersection, say) allocates nothing
+  float* d_stage_rays = nullptr;
+  ptk_hit* d_stage_hits = nullptr;
+  size_t stage_capacity = 0;  // in rays
   // counters and timing
   unsigned long long* d_counters = nullptr;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
@@ -601,6 +660,8 @@ int ptk_destroy(ptk_ctx* ctx)
   if (ctx->d_accum_own) (void)hipFree(ctx->d_accum_own);
   if (ctx->d_partial) (void)hipFree(ctx->d_partial);
   if (ctx->d_display) (void)hipFree(ctx->d_display);
+  if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
+  if (ctx->d_stage_hits) (void)hipFree(ctx->d_stage_hits);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -925,6 +986,8 @@ int ptk_intersect_batch_device(ptk_ctx* ctx, const float* device_rays, int32_t n
   if (!ctx) return PTK_ERR_INVALID;
   if (!ctx->have_scene) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch_device: upload a scene first");
   if (n < 0 || (n > 0 && (!device_rays || !device_hits))) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch_device: bad arguments");
+  if (((uintptr_t)device_rays & 7) || ((uintptr_t)device_hits & 3))
+    return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch_device: rays must be 8-byte aligned, hits 4-byte aligned");
   if (n == 0) return PTK_OK;
   PTK_HIP(hipSetDevice(ctx->device));
   return launch_intersect(ctx, device_rays, n, device_hits, false);
@@ -937,23 +1000,27 @@ int ptk_intersect_batch(ptk_ctx* ctx, const ptk_ray* rays, int32_t n, ptk_hit* h
   if (n < 0 || (n > 0 && (!rays || !hits))) return fail(ctx, PTK_ERR_INVALID, "ptk_intersect_batch: bad arguments");
   if (n == 0) return PTK_OK;
   PTK_HIP(hipSetDevice(ctx->device));
-  std::vector<float> fr(6 * (size_t)n);
+  if ((size_t)n > ctx->stage_capacity) {
+    PTK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
+    if (ctx->d_stage_hits) (void)hipFree(ctx->d_stage_hits);
+    ctx->d_stage_rays = nullptr; ctx->d_stage_hits = nullptr; ctx->stage_capacity = 0;
+    const size_t cap = std::max<size_t>((size_t)n, 64);
+    PTK_HIP(hipMalloc((void**)&ctx->d_stage_rays, cap * 6 * sizeof(float)));
+    PTK_HIP(hipMalloc((void**)&ctx->d_stage_hits, cap * sizeof(ptk_hit)));
+    ctx->stage_capacity = cap;
+  }
+  float one[6];
+  std::vector<float> many;
+  float* fr = one;
+  if (n > 1) { many.resize(6 * (size_t)n); fr = many.data(); }
   for (size_t i = 0; i < (size_t)n; i++)
     for (int k = 0; k < 3; k++) { fr[6 * i + k] = (float)rays[i].origin[k]; fr[6 * i + 3 + k] = (float)rays[i].direction[k]; }
-  float* d_rays = nullptr;
-  ptk_hit* d_hits = nullptr;
-  PTK_HIP(hipMalloc((void**)&d_rays, fr.size() * sizeof(float)));
-  hipError_t e = hipMalloc((void**)&d_hits, (size_t)n * sizeof(ptk_hit));
-  if (e != hipSuccess) { (void)hipFree(d_rays); ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return PTK_ERR_HIP; }
-  int rc = PTK_OK;
-  e = hipMemcpyAsync(d_rays, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) rc = launch_intersect(ctx, d_rays, n, d_hits, true);
-  if (e == hipSuccess && rc == PTK_OK) e = hipMemcpyAsync(hits, d_hits, (size_t)n * sizeof(ptk_hit), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && rc == PTK_OK) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_rays);
-  (void)hipFree(d_hits);
-  if (e != hipSuccess) { ctx->err = std::string("ptk_intersect_batch: ") + hipGetErrorString(e); return PTK_ERR_HIP; }
+  PTK_HIP(hipMemcpyAsync(ctx->d_stage_rays, fr, 6 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_intersect(ctx, ctx->d_stage_rays, n, ctx->d_stage_hits, true);
   if (rc) return rc;
+  PTK_HIP(hipMemcpyAsync(hits, ctx->d_stage_hits, (size_t)n * sizeof(ptk_hit), hipMemcpyDeviceToHost, ctx->stream));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));  // also covers `fr`: the copy in has completed
   return resolve_timing(ctx);
 }
 
@@ -969,6 +1036,11 @@ int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
     auto pct = [](unsigned long long lanes, unsigned long long iters) { return iters ? 100.0 * (double)lanes / (64.0 * (double)iters) : 0.0; };
     fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes\n",
             c[8], pct(c[9], c[8]), c[10], pct(c[11], c[10]), pct(c[12], c[10]), c[13], pct(c[14], c[13]));
+    const double tsum = (double)(c[16] + c[17] + c[18] + c[19] + c[20]);
+    if (tsum > 0)
+      fprintf(stderr, "[ptk phase clocks] descend %.1f%% (%.0f per wave-step) | leaves %.1f%% (%.0f) | lit %.1f%% | shade %.1f%% (%.0f per shade step) | refill %.1f%%\n",
+              100.0 * c[16] / tsum, c[8] ? (double)c[16] / c[8] : 0.0, 100.0 * c[17] / tsum, c[10] ? (double)c[17] / c[10] : 0.0,
+              100.0 * c[18] / tsum, 100.0 * c[19] / tsum, c[13] ? (double)c[19] / c[13] : 0.0, 100.0 * c[20] / tsum);
   })
   out->kernel_ms_last = ctx->ms_last; out->kernel_ms_total = ctx->ms_total; out->launches = ctx->launches;
   return PTK_OK;

@@ -3,7 +3,7 @@
 # all on a short run of bench.py.  Usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS="${@:---spp 32 --steps 2 --warmup 1 --no-cpu}"
+ARGS="${@:---workload bunny --spp 32 --steps 2 --warmup 1 --no-cpu}"
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

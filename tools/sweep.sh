@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: run bench.py once per library variant; one JSON line per variant in gpurun_out/sweep_<tag>.jsonl
 TAG=${1:-sweep}; shift
-ARGS="${@:---spp 64 --steps 3 --warmup 1 --no-cpu}"
+ARGS="${@:---workload bunny --spp 64 --steps 3 --warmup 1 --no-cpu}"
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/sweep_$TAG.jsonl
 : > $OUT

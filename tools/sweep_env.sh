@@ -2,7 +2,7 @@
 # On the GPU box: run bench.py once per value of an environment variable.
 #   tools/sweep_env.sh <tag> <VAR> "<v1 v2 ...>" [bench args]
 TAG=$1; VAR=$2; VALUES=$3; shift 3
-ARGS="${@:---spp 64 --steps 3 --warmup 1 --no-cpu}"
+ARGS="${@:---workload bunny --spp 64 --steps 3 --warmup 1 --no-cpu}"
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/sweep_$TAG.jsonl
 : > $OUT

@@ -234,6 +234,45 @@ int ptk_reset_stats(ptk_ctx* ctx);
  * work after it. */
 void* ptk_stream(ptk_ctx* ctx);
 
+/* -- several GPUs behind one handle.  The reference's only parallel construct is the OpenMP loop over image
+ * rows inside Renderer::render (src/renderer.cpp:31-32); its caller (src/main.cpp:236-255) is one thread that
+ * calls render() in a loop and save_image() between batches.  A group keeps that calling pattern and spreads
+ * each render call over the GPUs of a node from the one calling thread: one context and one stream per device,
+ * no exchange while rendering, and ONE collective (an RCCL sum-reduce of the per-device (sum r, g, b, count)
+ * buffers onto device 0, over xGMI) each time the frame is read.  The per-device buffers keep accumulating
+ * across render calls (Renderer::total_samples semantics), whatever the split.
+ *   PTK_SPLIT_SAMPLES  every device renders every pixel; device i takes the call's samples i, i+n, i+2n, ...
+ *                      (global sample indices: the union is exactly what one GPU would render)
+ *   PTK_SPLIT_BANDS    device i renders all samples of the 16-row bands i, i+n, i+2n, ... of the image
+ * With one device a group is a thin wrapper of that device's context.  `devices` names each GPU once.
+ * (Naming ONE device several times is allowed for testing the group logic on a one-GPU machine: those
+ * contexts share the GPU and their buffers are added by a kernel instead of a collective.)
+ * ptk_group_context gives the context of the index-th device, e.g. for ptk_get_stats, ptk_scene_info_get or
+ * ptk_intersect_batch; do not render, bind or change the scene through it.  librccl.so is loaded when the
+ * first group of two or more GPUs is created. */
+typedef struct ptk_group ptk_group;
+#define PTK_SPLIT_SAMPLES 0
+#define PTK_SPLIT_BANDS 1
+int ptk_group_create(const int* devices, int n_devices, ptk_group** out);
+int ptk_group_destroy(ptk_group* group);
+/* message of the last failing call on group (or of the last failing ptk_group_create when group is NULL) */
+const char* ptk_group_last_error(const ptk_group* group);
+int ptk_group_size(const ptk_group* group);
+ptk_ctx* ptk_group_context(ptk_group* group, int index);
+/* Scene::compute_bvh for every device: the scene is flattened (and a host tree built) once and copied to each
+ * GPU; builder as in ptk_upload_scene_ex. */
+int ptk_group_upload_scene(ptk_group* group, const ptk_scene_desc* scene, int32_t builder);
+int ptk_group_set_camera(ptk_group* group, const ptk_camera* camera);
+int ptk_group_set_flags(ptk_group* group, const ptk_flags* flags);
+int ptk_group_reset_accum(ptk_group* group);
+/* Renderer::render over all devices; asynchronous.  params describes the whole call (samples = the call's total);
+ * with the band split leave row_begin, row_end and band_* zero. */
+int ptk_group_render(ptk_group* group, const ptk_render_params* params, int32_t split);
+int ptk_group_synchronize(ptk_group* group);
+/* ptk_read_accum / ptk_read_display_u8 of the whole frame: reduce onto device 0, then read.  Block. */
+int ptk_group_read_accum(ptk_group* group, float* rgb, int32_t* total_samples);
+int ptk_group_read_display_u8(ptk_group* group, uint8_t* rgb8, int32_t* total_samples);
+
 #ifdef __cplusplus
 }
 #endif

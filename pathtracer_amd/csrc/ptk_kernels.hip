@@ -505,6 +505,8 @@ struct ptk_ctx {
   std::string err;
   // scene
   bool have_scene = false;
+  bool have_scene_host = false;  // `host` still holds everything another context would need (ctx_upload_like)
+  int32_t builder_asked = 0;
   HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
   SceneView view;
   void* d_nodes = nullptr; void* d_prims = nullptr; void* d_shade = nullptr; void* d_materials = nullptr;
@@ -622,6 +624,95 @@ static int pick_chunks(int n_tiles, int samples)
   return (int)std::max<int64_t>(c, 1);
 }
 
+static void release_host_copy(ptk_ctx* ctx)
+{
+  std::vector<uint8_t>().swap(ctx->host.texels);
+  std::vector<float>().swap(ctx->host.prim_boxes);
+  if (ctx->builder == PTK_BUILDER_DEVICE_LBVH) std::vector<PrimRec>().swap(ctx->host.prims);  // id order: not the device's order
+  ctx->have_scene_host = false;
+}
+
+// Second half of an upload: ctx->host holds the flattened scene (build_host_scene); build the tree on the device
+// if that was asked for, copy everything to the GPU.  keep_host: leave the host copy whole (texels, boxes) so that
+// another context of a group can be given the same scene (ctx_upload_like).
+static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  HostScene& h = ctx->host;
+  const bool on_device = !h.prim_boxes.empty();  // small scenes get their tree on the host whatever was asked
+  ctx->builder = on_device ? PTK_BUILDER_DEVICE_LBVH : PTK_BUILDER_HOST_SAH;
+  ctx->builder_asked = builder;
+  int rc;
+  if (on_device) {
+    void *d_boxes = nullptr, *d_by_id = nullptr;
+    if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) { if (d_boxes) (void)hipFree(d_boxes); return rc; }
+    if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); if (d_by_id) (void)hipFree(d_by_id); return rc; }
+    DeviceTree tree;
+    std::string why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
+                                        h.centroid_hi, h.max_diagonal, h.grid, tree);
+    (void)hipFree(d_boxes);
+    (void)hipFree(d_by_id);
+    if (!why.empty()) return fail(ctx, PTK_ERR_HIP, "ptk_upload_scene: " + why);
+    ctx->d_nodes = tree.nodes;
+    ctx->d_prims = tree.prims;
+    h.max_depth = tree.max_depth;
+    h.max_leaf = tree.max_leaf;
+    ctx->n_nodes = tree.n_nodes;
+    ctx->tree_ms = tree.build_ms;
+  } else {
+    ctx->n_nodes = (int32_t)h.nodes.size();
+    ctx->tree_ms = 0.0;
+  }
+  // the kernels' per-lane stacks hold kStackDepth entries: a sentinel, one per level, one of scratch
+  if (h.max_depth > kMaxTreeDepth || kMaxTreeDepth + 2 > kStackDepth) {
+    free_scene(ctx);
+    return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
+  }
+  if (!on_device) {
+    if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
+    if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
+  }
+  if ((rc = upload(ctx, &ctx->d_shade, h.shade))) return rc;
+  if ((rc = upload(ctx, &ctx->d_materials, h.materials))) return rc;
+  if ((rc = upload(ctx, &ctx->d_lights, h.lights))) return rc;
+  if ((rc = upload(ctx, &ctx->d_textures, h.textures))) return rc;
+  if ((rc = upload(ctx, &ctx->d_texels, h.texels))) return rc;
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  SceneView v = h.host_view();
+  v.n_nodes = ctx->n_nodes;
+  v.nodes = (const NodePair*)ctx->d_nodes;
+  v.prims = (const PrimRec*)ctx->d_prims;
+  v.shade = (const ShadeRec*)ctx->d_shade;
+  v.materials = (const MaterialRec*)ctx->d_materials;
+  v.lights = (const LightRec*)ctx->d_lights;
+  v.textures = (const TextureRec*)ctx->d_textures;
+  v.texels = (const uint8_t*)ctx->d_texels;
+  ctx->view = v;
+  ctx->texel_bytes = h.texels.size();
+  ctx->have_scene_host = keep_host;
+  if (!keep_host) release_host_copy(ctx);  // the largest host copies are no longer needed
+  ctx->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->have_scene = true;
+  return PTK_OK;
+}
+
+static int upload_scene_impl(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder, bool keep_host)
+{
+  if (!ctx) return PTK_ERR_INVALID;
+  if (!scene) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: scene is NULL");
+  if (builder != PTK_BUILDER_HOST_SAH && builder != PTK_BUILDER_DEVICE_LBVH)
+    return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: unknown builder");
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  free_scene(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::string why = build_host_scene(*scene, ctx->host, builder == PTK_BUILDER_HOST_SAH);
+  if (!why.empty()) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: " + why);
+  ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return finish_upload(ctx, builder, keep_host);
+}
+
+
 extern "C" {
 
 int ptk_create(int device, ptk_ctx** out)
@@ -674,72 +765,7 @@ const char* ptk_last_error(const ptk_ctx* ctx) { return ctx ? ctx->err.c_str() :
 
 int ptk_upload_scene_ex(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder)
 {
-  if (!ctx) return PTK_ERR_INVALID;
-  if (!scene) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: scene is NULL");
-  if (builder != PTK_BUILDER_HOST_SAH && builder != PTK_BUILDER_DEVICE_LBVH)
-    return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: unknown builder");
-  PTK_HIP(hipSetDevice(ctx->device));
-  PTK_HIP(hipStreamSynchronize(ctx->stream));
-  free_scene(ctx);
-  const auto t0 = std::chrono::steady_clock::now();
-  std::string why = build_host_scene(*scene, ctx->host, builder == PTK_BUILDER_HOST_SAH);
-  if (!why.empty()) return fail(ctx, PTK_ERR_INVALID, "ptk_upload_scene: " + why);
-  HostScene& h = ctx->host;
-  const bool on_device = !h.prim_boxes.empty();  // small scenes get their tree on the host whatever was asked
-  ctx->builder = on_device ? PTK_BUILDER_DEVICE_LBVH : PTK_BUILDER_HOST_SAH;
-  int rc;
-  if (on_device) {
-    void *d_boxes = nullptr, *d_by_id = nullptr;
-    if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) { if (d_boxes) (void)hipFree(d_boxes); return rc; }
-    if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); if (d_by_id) (void)hipFree(d_by_id); return rc; }
-    DeviceTree tree;
-    why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
-                            h.centroid_hi, h.max_diagonal, h.grid, tree);
-    (void)hipFree(d_boxes);
-    (void)hipFree(d_by_id);
-    if (!why.empty()) return fail(ctx, PTK_ERR_HIP, "ptk_upload_scene: " + why);
-    ctx->d_nodes = tree.nodes;
-    ctx->d_prims = tree.prims;
-    h.max_depth = tree.max_depth;
-    h.max_leaf = tree.max_leaf;
-    ctx->n_nodes = tree.n_nodes;
-    ctx->tree_ms = tree.build_ms;
-    std::vector<float>().swap(h.prim_boxes);
-    std::vector<PrimRec>().swap(h.prims);  // id order: not the device's order, so not kept
-  } else {
-    ctx->n_nodes = (int32_t)h.nodes.size();
-    ctx->tree_ms = 0.0;
-  }
-  // the kernels' per-lane stacks hold kStackDepth entries: a sentinel, one per level, one of scratch
-  if (h.max_depth > kMaxTreeDepth || kMaxTreeDepth + 2 > kStackDepth) {
-    free_scene(ctx);
-    return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
-  }
-  if (!on_device) {
-    if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
-    if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
-  }
-  if ((rc = upload(ctx, &ctx->d_shade, h.shade))) return rc;
-  if ((rc = upload(ctx, &ctx->d_materials, h.materials))) return rc;
-  if ((rc = upload(ctx, &ctx->d_lights, h.lights))) return rc;
-  if ((rc = upload(ctx, &ctx->d_textures, h.textures))) return rc;
-  if ((rc = upload(ctx, &ctx->d_texels, h.texels))) return rc;
-  PTK_HIP(hipStreamSynchronize(ctx->stream));
-  SceneView v = h.host_view();
-  v.n_nodes = ctx->n_nodes;
-  v.nodes = (const NodePair*)ctx->d_nodes;
-  v.prims = (const PrimRec*)ctx->d_prims;
-  v.shade = (const ShadeRec*)ctx->d_shade;
-  v.materials = (const MaterialRec*)ctx->d_materials;
-  v.lights = (const LightRec*)ctx->d_lights;
-  v.textures = (const TextureRec*)ctx->d_textures;
-  v.texels = (const uint8_t*)ctx->d_texels;
-  ctx->view = v;
-  ctx->texel_bytes = h.texels.size();
-  std::vector<uint8_t>().swap(h.texels);  // the largest host copy is no longer needed
-  ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  ctx->have_scene = true;
-  return PTK_OK;
+  return upload_scene_impl(ctx, scene, builder, false);
 }
 
 int ptk_upload_scene(ptk_ctx* ctx, const ptk_scene_desc* scene)
@@ -1060,3 +1086,28 @@ int ptk_reset_stats(ptk_ctx* ctx)
 void* ptk_stream(ptk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 }  // extern "C"
+
+// ---- hooks for ptk_group.hip (ptk_internal.h) -------------------------------------------------------------
+namespace ptk {
+
+int ctx_device(const ptk_ctx* ctx) { return ctx->device; }
+float* ctx_accum(ptk_ctx* ctx) { return reinterpret_cast<float*>(ctx->d_accum); }
+size_t ctx_accum_pixels(const ptk_ctx* ctx) { return ctx->have_camera ? ctx->accum_pixels : 0; }
+void ctx_set_error(ptk_ctx* ctx, const std::string& msg) { ctx->err = msg; }
+int ctx_upload_keep_host(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder) { return upload_scene_impl(ctx, scene, builder, true); }
+void ctx_release_host_copy(ptk_ctx* ctx) { release_host_copy(ctx); }
+
+// Gives `to` the scene that `from` holds on the host side (the flattened records and, for a host-built tree,
+// the tree) and uploads it to `to`'s GPU: the tree is built once for all GPUs of a group.
+int ctx_upload_like(ptk_ctx* to, ptk_ctx* from)
+{
+  ptk_ctx* ctx = to;
+  if (!from->have_scene_host) return fail(ctx, PTK_ERR_INVALID, "ptk_group_upload_scene: the first context holds no scene");
+  PTK_HIP(hipSetDevice(ctx->device));
+  PTK_HIP(hipStreamSynchronize(ctx->stream));
+  free_scene(ctx);
+  ctx->host = from->host;
+  return finish_upload(ctx, from->builder_asked);
+}
+
+}  // namespace ptk

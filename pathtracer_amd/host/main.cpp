@@ -1,16 +1,23 @@
-// pt: the command-line driver, same arguments, JSON keys and console output as the reference's
-// src/main.cpp:172-270:
-//   pt <config.json> <output.png> [samples=8] [bounces=3] [batch_size=16]
+// pt -- command-line front end of the GPU render path.
+//
+// The command line, the JSON keys with their defaults and the lines printed are the reference's
+// (src/main.cpp:68-111 keys, :174-210 arguments, :227-266 output), so that scripts and configuration files
+// written for it keep working:
+//
+//   pt <config.json> <output.png> [samples=8] [bounces=3] [batch_size=16] [--gpus N] [--split spp|tile] [--seed S]
+//
+// The scene is assembled straight from the JSON document into Scene / Camera calls; the three flags are
+// additions (GPUs 0..N-1 of the node share every render call; see Scene::group()).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <memory>
-#include <sstream>
 #include <string>
-#include <tuple>
 #include <vector>
 
 #include "geometry.h"
@@ -20,198 +27,207 @@
 #include "renderer.h"
 #include "scene.h"
 
+namespace {
+
+namespace fs = std::filesystem;
 using pt::Json;
 
-struct SimpleSphere : public Sphere {
-  Material::Type type;
-  pt::dvec3 albedo;
-  pt::dvec3 emissive;
-  std::string texture;
-  double metallic;
-  double roughness;
-  bool hidden;
+struct CommandLine {
+  fs::path config, output;
+  int samples = 8, bounces = 3, batch = 16;  // src/main.cpp:194-210
+  int gpus = 0;                              // 0: leave PT_DEVICES / PT_DEVICE as they are
+  std::string split;
+  const char* seed = nullptr;
 };
 
-struct Config {
-  bool print_progress;
-  int max_bounce;
-  int samples_per_pixel;
-  int batch_size;
-  int image_width;
-  int image_height;
-  pt::dvec3 camera_position;
-  pt::dvec3 camera_target;
-  double camera_fov;
-  double camera_aperture;
-  double camera_focus_distance;
-  std::vector<std::string> models;
-  std::vector<SimpleSphere> spheres;
-  std::string background_texture;
-  pt::dvec3 background_color;
+// Positional arguments in the reference's order, flags anywhere.  Returns false when the two required paths are missing.
+bool read_command_line(int argc, char** argv, CommandLine& cl)
+{
+  std::vector<const char*> positional;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    const bool has_value = i + 1 < argc;
+    if (a == "--gpus" && has_value) cl.gpus = std::atoi(argv[++i]);
+    else if (a == "--split" && has_value) cl.split = argv[++i];
+    else if (a == "--seed" && has_value) cl.seed = argv[++i];
+    else positional.push_back(argv[i]);
+  }
+  if (positional.size() < 2) return false;
+  cl.config = positional[0];
+  cl.output = positional[1];
+  int* numbers[] = {&cl.samples, &cl.bounces, &cl.batch};
+  for (size_t k = 0; k < 3 && k + 2 < positional.size(); k++) *numbers[k] = std::atoi(positional[k + 2]);
+  return true;
+}
+
+// Typed access to one JSON object with the reference's "key missing -> default" rule (src/main.cpp:50-66).
+class Fields
+{
+ public:
+  explicit Fields(const Json& object) : m_object(object) {}
+  double number(const char* key, double otherwise) const { return has(key) ? m_object[key].number() : otherwise; }
+  bool flag(const char* key, bool otherwise) const { return has(key) ? m_object[key].boolean() : otherwise; }
+  std::string text(const char* key) const { return has(key) ? m_object[key].string() : std::string(); }
+  pt::dvec3 vector(const char* key, pt::dvec3 otherwise) const
+  {
+    if (!has(key)) return otherwise;
+    const Json& v = m_object[key];
+    return pt::dvec3(v["x"].number(), v["y"].number(), v["z"].number());
+  }
+  const std::vector<Json>& list(const char* key) const
+  {
+    static const std::vector<Json> none;
+    return has(key) ? m_object[key].arr : none;
+  }
+
+ private:
+  bool has(const char* key) const { return m_object.contains(key); }
+  const Json& m_object;
 };
 
-static pt::dvec3 vec_or(const Json& j, const std::string& key, pt::dvec3 def)
+// "models": OBJ files, in order; their triangles take the first primitive ids (src/main.cpp:117-122)
+void add_models(Scene& scene, const Fields& config)
 {
-  if (!j.contains(key)) return def;
-  const Json& v = j[key];
-  return pt::dvec3(v["x"].number(), v["y"].number(), v["z"].number());
-}
-static double num_or(const Json& j, const std::string& key, double def) { return j.contains(key) ? j[key].number() : def; }
-static bool bool_or(const Json& j, const std::string& key, bool def) { return j.contains(key) ? j[key].boolean() : def; }
-static std::string str_or(const Json& j, const std::string& key, const std::string& def) { return j.contains(key) ? j[key].string() : def; }
-
-// keys and defaults of src/main.cpp:68-87
-static SimpleSphere sphere_from_json(const Json& j)
-{
-  SimpleSphere s;
-  s.hidden = bool_or(j, "hidden", false);
-  s.center = vec_or(j, "center", pt::dvec3(0.0));
-  s.radius = num_or(j, "radius", 1.0);
-  s.albedo = vec_or(j, "albedo", pt::dvec3(1.0));
-  s.emissive = vec_or(j, "emissive", pt::dvec3(0.0));
-  s.texture = str_or(j, "texture", std::string());
-  s.metallic = num_or(j, "metallic", 0.5);
-  s.roughness = num_or(j, "roughness", 0.5);
-  std::string type = str_or(j, "type", "DIFFUSE");
-  if (type == "SPECULAR") s.type = Material::SPECULAR;
-  else if (type == "TRANSMISSIVE") s.type = Material::DIELECTRIC;
-  else s.type = Material::DIFFUSE;
-  return s;
-}
-
-// keys and defaults of src/main.cpp:89-111
-static Config config_from_json(const Json& j)
-{
-  Config c{};
-  c.print_progress = bool_or(j, "print_progress", false);
-  c.image_width = (int)num_or(j, "image_width", 640);
-  c.image_height = (int)num_or(j, "image_height", 480);
-  c.camera_position = vec_or(j, "camera_position", pt::dvec3(0.0, 0.0, 10.0));
-  c.camera_target = vec_or(j, "camera_target", pt::dvec3(0.0, 0.0, 0.0));
-  c.camera_fov = num_or(j, "camera_fov", 45);
-  c.camera_aperture = num_or(j, "camera_aperture", 0);
-  c.camera_focus_distance = num_or(j, "camera_focus_distance", 0);
-  c.background_texture = str_or(j, "background_texture", std::string());
-  c.background_color = vec_or(j, "background_color", pt::dvec3(-1.0));
-  if (j.contains("models"))
-    for (const Json& m : j["models"].arr) c.models.push_back(m.string());
-  if (j.contains("spheres"))
-    for (const Json& s : j["spheres"].arr) c.spheres.push_back(sphere_from_json(s));
-  return c;
-}
-
-// src/main.cpp:113-170
-static std::tuple<std::unique_ptr<Scene>, std::unique_ptr<Camera>> setup_scene(const Config& config)
-{
-  auto scene = std::make_unique<Scene>();
-  for (const std::string& path : config.models) {
-    auto mesh = scene->load_obj(path);
-    AABB bbox = compute_bounding_volume(mesh.begin(), mesh.end());
-    std::cout << "Mesh Size: " << bbox.size() << ", Mesh Center: " << bbox.center() << std::endl;
-    scene->add_primitives(mesh.begin(), mesh.end());
+  for (const Json& entry : config.list("models")) {
+    std::vector<Primitive> mesh = scene.load_obj(entry.string());
+    const AABB box = compute_bounding_volume(mesh.begin(), mesh.end());
+    std::cout << "Mesh Size: " << box.size() << ", Mesh Center: " << box.center() << std::endl;
+    scene.add_primitives(mesh.begin(), mesh.end());
   }
-  for (const auto& s : config.spheres) {
-    if (s.hidden) continue;
-    Material* material = scene->add_material(Material());
-    material->type = s.type;
-    material->albedo = s.albedo;
-    material->emission = s.emissive;
-    material->roughness = s.roughness;
-    material->metallic = s.metallic;
-    if (!s.texture.empty()) {
-      material->texture = new Image();  // lives as long as the process
-      if (material->texture->load(s.texture)) std::cout << "Loaded texture " << s.texture << std::endl;
-      else std::cerr << "Failed to load texture " << s.texture << std::endl;
+}
+
+// "spheres": one material and one primitive each unless "hidden" (src/main.cpp:68-87 keys, :124-145 set-up)
+void add_spheres(Scene& scene, const Fields& config)
+{
+  for (const Json& entry : config.list("spheres")) {
+    const Fields s(entry);
+    if (s.flag("hidden", false)) continue;
+    Material* m = scene.add_material(Material());
+    const std::string type = s.text("type");
+    m->type = type == "SPECULAR" ? Material::SPECULAR : type == "TRANSMISSIVE" ? Material::DIELECTRIC : Material::DIFFUSE;
+    m->albedo = s.vector("albedo", pt::dvec3(1.0));
+    m->emission = s.vector("emissive", pt::dvec3(0.0));
+    m->roughness = s.number("roughness", 0.5);
+    m->metallic = s.number("metallic", 0.5);
+    const std::string texture = s.text("texture");
+    if (!texture.empty()) {
+      Image* image = new Image();  // owned by nobody, like every material texture (Material::texture is a plain pointer)
+      const bool ok = image->load(texture);
+      (ok ? std::cout << "Loaded texture " : std::cerr << "Failed to load texture ") << texture << std::endl;
+      m->texture = image;
     }
-    Primitive p(Sphere(s.center, s.radius), material);
-    scene->add_primitive(p);
+    scene.add_primitive(Primitive(Sphere(s.vector("center", pt::dvec3(0.0)), s.number("radius", 1.0)), m));
   }
-  if (!config.background_texture.empty()) {
-    auto image = std::make_unique<Image>();
-    if (image->load(config.background_texture)) {
-      std::cout << "Loaded environment texture " << config.background_texture << std::endl;
-      scene->set_background_texture(std::move(image));
-    } else {
-      std::cerr << "Failed to load environment texture " << config.background_texture << std::endl;
-      exit(1);
-    }
+}
+
+// "background_texture" wins over "background_color" (src/main.cpp:147-158); an unreadable map ends the run
+void set_background(Scene& scene, const Fields& config)
+{
+  const std::string map = config.text("background_texture");
+  if (map.empty()) {
+    scene.set_background_color(config.vector("background_color", pt::dvec3(-1.0)));
+    return;
+  }
+  auto image = std::make_unique<Image>();
+  if (!image->load(map)) {
+    std::cerr << "Failed to load environment texture " << map << std::endl;
+    std::exit(1);
+  }
+  std::cout << "Loaded environment texture " << map << std::endl;
+  scene.set_background_texture(std::move(image));
+}
+
+std::unique_ptr<Camera> make_camera(const Fields& config)
+{
+  auto camera = std::make_unique<Camera>((int)config.number("image_width", 640), (int)config.number("image_height", 480),
+                                         config.number("camera_fov", 45), config.number("camera_aperture", 0),
+                                         config.number("camera_focus_distance", 0));
+  const pt::dvec3 position = config.vector("camera_position", pt::dvec3(0.0, 0.0, 10.0));
+  const pt::dvec3 target = config.vector("camera_target", pt::dvec3(0.0, 0.0, 0.0));
+  camera->look_at(position, target);
+  std::cout << "Distance camera position to camera target: " << pt::distance(position, target) << std::endl;
+  return camera;
+}
+
+// Renders in batches with a preview file after each (src/main.cpp:242-255); returns the seconds it took.
+double render_all(Renderer& renderer, const CommandLine& cl, bool progress)
+{
+  const auto begin = std::chrono::steady_clock::now();
+  if (cl.batch <= 0) {
+    renderer.render(cl.samples, progress);
   } else {
-    scene->set_background_color(config.background_color);
+    const fs::path preview = cl.output.parent_path() / "latest.png";
+    while (renderer.total_samples < cl.samples) {
+      renderer.render(std::min(cl.batch, cl.samples - renderer.total_samples), progress);
+      std::printf("%d/%d samples per pixel\n", renderer.total_samples, cl.samples);
+      renderer.save_image(preview);
+    }
   }
-  auto camera = std::make_unique<Camera>(config.image_width, config.image_height, config.camera_fov,
-                                         config.camera_aperture, config.camera_focus_distance);
-  camera->look_at(config.camera_position, config.camera_target);
-  std::cout << "Distance camera position to camera target: " << pt::distance(config.camera_position, config.camera_target)
-            << std::endl;
-  scene->compute_bvh();
-  return std::make_tuple(std::move(scene), std::move(camera));
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
 }
+
+}  // namespace
 
 int main(int argc, char** argv)
 {
-  if (argc < 3) {
+  CommandLine cl;
+  if (!read_command_line(argc, argv, cl)) {
     std::cerr << "Usage: " << argv[0] << " <path to config.json> <output path> <samples> <bounces> <batch_size>" << std::endl;
     return 1;
   }
-  std::filesystem::path config_path = std::filesystem::path(argv[1]);
-  std::filesystem::path result_path = std::filesystem::path(argv[2]);
-  std::ifstream file(config_path);
+  std::ifstream file(cl.config);
   if (!file.is_open()) {
-    std::cerr << "Could not open config: " << config_path.string() << std::endl;
+    std::cerr << "Could not open config: " << cl.config.string() << std::endl;
     return 1;
   }
-  std::stringstream buffer;
-  buffer << file.rdbuf();
-  Config config;
+  const std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+  Json document;
   try {
-    std::string text = buffer.str();
-    config = config_from_json(pt::JsonParser(text).parse());
+    document = pt::JsonParser(text).parse();
   } catch (const std::exception& e) {
     std::cerr << "Could not parse config: " << e.what() << std::endl;
     return 1;
   }
-  config.samples_per_pixel = 4 <= argc ? std::atoi(argv[3]) : 8;
-  config.max_bounce = 5 <= argc ? std::atoi(argv[4]) : 3;
-  config.batch_size = 6 <= argc ? std::atoi(argv[5]) : 16;
+  if (cl.gpus > 0) {
+    std::string list;
+    for (int d = 0; d < cl.gpus; d++) list += (d ? "," : "") + std::to_string(d);
+    setenv("PT_DEVICES", list.c_str(), 1);
+  }
+  if (!cl.split.empty()) setenv("PT_SPLIT", cl.split.c_str(), 1);
+  if (!cl.seed) cl.seed = std::getenv("PT_SEED");
 
-  auto [scene, camera] = setup_scene(config);
+  Scene scene;
+  std::unique_ptr<Camera> camera;
+  bool progress = false;
+  try {
+    const Fields config(document);
+    progress = config.flag("print_progress", false);
+    add_models(scene, config);
+    add_spheres(scene, config);
+    set_background(scene, config);
+    camera = make_camera(config);
+  } catch (const std::exception& e) {
+    std::cerr << "Could not parse config: " << e.what() << std::endl;
+    return 1;
+  }
+  scene.compute_bvh();
 
-  std::cout << "Samples Per Pixel: " << config.samples_per_pixel << std::endl;
-  std::cout << "Max Bounce Depth: " << config.max_bounce << std::endl;
+  std::cout << "Samples Per Pixel: " << cl.samples << std::endl;
+  std::cout << "Max Bounce Depth: " << cl.bounces << std::endl;
   std::cout << "Camera Position: " << camera->position() << std::endl;
   std::cout << "Camera Direction: " << camera->direction() << std::endl;
   std::cout << "Camera Resolution: " << camera->resolution() << std::endl;
-  std::cout << "Scene Size: " << scene->size() << std::endl;
-  std::cout << "Scene Center: " << scene->center() << std::endl;
-  std::cout << "Primitive Count: " << scene->primitive_count() << std::endl;
+  std::cout << "Scene Size: " << scene.size() << std::endl;
+  std::cout << "Scene Center: " << scene.center() << std::endl;
+  std::cout << "Primitive Count: " << scene.primitive_count() << std::endl;
 
-  Renderer renderer(camera.get(), scene.get(), config.max_bounce);
-  if (const char* seed = std::getenv("PT_SEED")) renderer.set_seed((uint32_t)std::strtoul(seed, nullptr, 10));
-
-  auto start = std::chrono::high_resolution_clock::now();
-  int batch = config.batch_size;
-  if (0 < batch) {
-    while (renderer.total_samples < config.samples_per_pixel) {
-      int todo = config.samples_per_pixel - renderer.total_samples;
-      if (batch > todo) batch = todo;
-      renderer.render(batch, config.print_progress);
-      printf("%d/%d samples per pixel\n", renderer.total_samples, config.samples_per_pixel);
-      auto path = result_path.parent_path() / std::filesystem::path("latest.png");
-      renderer.save_image(path);
-    }
-  } else {
-    renderer.render(config.samples_per_pixel, config.print_progress);
-  }
-  auto end = std::chrono::high_resolution_clock::now();
-  std::chrono::duration<double, std::milli> duration = end - start;
-  double seconds = duration.count() / 1000.0;
-  int minutes = (int)(seconds / 60);
-  seconds -= (minutes * 60);
+  Renderer renderer(camera.get(), &scene, cl.bounces);
+  if (cl.seed) renderer.set_seed((uint32_t)std::strtoul(cl.seed, nullptr, 10));
+  const double seconds = render_all(renderer, cl, progress);
 
   print_stats();
-  printf("%d Samples/Pixel\n", renderer.total_samples);
-  fprintf(stdout, "Render time: %dm%.3fs\n", minutes, seconds);
-
-  renderer.save_image(result_path);
+  std::printf("%d Samples/Pixel\n", renderer.total_samples);
+  std::printf("Render time: %dm%.3fs\n", (int)(seconds / 60.0), seconds - 60.0 * (int)(seconds / 60.0));
+  renderer.save_image(cl.output);
   return 0;
 }

@@ -47,7 +47,7 @@ void register_stats_scene(const Scene* s);
 Scene::~Scene()
 {
   register_stats_scene(nullptr);
-  if (m_ctx) ptk_destroy(m_ctx);
+  if (m_group) ptk_group_destroy(m_group);
 }
 
 void Scene::set_background_texture(std::unique_ptr<Image> texture) { m_background_texture = std::move(texture); }
@@ -179,13 +179,28 @@ std::vector<Primitive> Scene::load_obj(const std::filesystem::path& filename)
 void Scene::compute_bvh()
 {
   m_bounds = compute_bounding_volume(m_primitives.begin(), m_primitives.end());
-  if (!m_ctx) {
-    int device = 0;
-    if (const char* e = std::getenv("PT_DEVICE")) device = std::atoi(e);
-    if (ptk_create(device, &m_ctx) != PTK_OK) {
-      std::cerr << "Scene::compute_bvh: " << ptk_last_error(nullptr) << std::endl;
+  if (!m_group) {
+    std::vector<int> devices;
+    if (const char* e = std::getenv("PT_DEVICES")) {  // "0,1,2,3"
+      for (const char* q = e; *q;) {
+        char* end = nullptr;
+        long v = std::strtol(q, &end, 10);
+        if (end == q) break;
+        devices.push_back((int)v);
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' && *end != 0) break;
+      }
+    }
+    if (devices.empty()) {
+      const char* e = std::getenv("PT_DEVICE");
+      devices.push_back(e ? std::atoi(e) : 0);
+    }
+    if (const char* e = std::getenv("PT_SPLIT")) m_split = (std::string(e) == "tile") ? PTK_SPLIT_BANDS : PTK_SPLIT_SAMPLES;
+    if (ptk_group_create(devices.data(), (int)devices.size(), &m_group) != PTK_OK) {
+      std::cerr << "Scene::compute_bvh: " << ptk_group_last_error(nullptr) << std::endl;
       std::exit(1);
     }
+    m_ctx = ptk_group_context(m_group, 0);
   }
   std::vector<double> tri_pos, tri_nrm, tri_uv, sph_c, sph_r;
   std::vector<int32_t> tri_mat, sph_mat;
@@ -249,8 +264,10 @@ void Scene::compute_bvh()
   d.textures = texs.data();
   d.background_texture = background;
   d.background_color[0] = m_background_color.x; d.background_color[1] = m_background_color.y; d.background_color[2] = m_background_color.z;
-  if (ptk_upload_scene(m_ctx, &d) != PTK_OK) {
-    std::cerr << "Scene::compute_bvh: " << ptk_last_error(m_ctx) << std::endl;
+  int32_t builder = PTK_BUILDER_HOST_SAH;
+  if (const char* e = std::getenv("PTK_BUILDER")) builder = (std::string(e) == "device") ? PTK_BUILDER_DEVICE_LBVH : PTK_BUILDER_HOST_SAH;
+  if (ptk_group_upload_scene(m_group, &d, builder) != PTK_OK) {
+    std::cerr << "Scene::compute_bvh: " << ptk_group_last_error(m_group) << std::endl;
     std::exit(1);
   }
   register_stats_scene(this);

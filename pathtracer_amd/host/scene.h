@@ -20,6 +20,7 @@
 #include "vec.h"
 
 struct ptk_ctx;
+struct ptk_group;
 
 class Scene
 {
@@ -45,8 +46,12 @@ class Scene
   int light_count() const;
   std::vector<Primitive> lights() const;
 
-  // The GPU context the scene lives in after compute_bvh() (GPU index from PT_DEVICE, default 0).
+  // Where the scene lives after compute_bvh(): a group of GPUs (PT_DEVICES=0,1,... in the environment; one GPU,
+  // PT_DEVICE or 0, when that is unset) and the context of the group's first GPU, which answers ray queries.
+  ptk_group* group() const { return m_group; }
   ptk_ctx* context() const { return m_ctx; }
+  // How Renderer::render shares a frame between the group's GPUs: PTK_SPLIT_SAMPLES unless PT_SPLIT=tile.
+  int split() const { return m_split; }
   // Number of box / primitive tests etc. since the scene was uploaded (print_stats, src/geometry.cpp:273-278)
   void print_stats() const;
 
@@ -59,5 +64,7 @@ class Scene
   std::unique_ptr<Image> m_background_texture;
   pt::dvec3 m_background_color;
   AABB m_bounds;
-  ptk_ctx* m_ctx = nullptr;
+  ptk_group* m_group = nullptr;
+  ptk_ctx* m_ctx = nullptr;  // m_group's first context
+  int m_split = 0;
 };

@@ -89,7 +89,11 @@ assert HIT_DTYPE.itemsize == 52
 # every symbol include/ptk.h declares
 EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "ptk_upload_scene_ex", "ptk_scene_info_get", "ptk_set_camera",
            "ptk_set_flags", "ptk_bind_accum", "ptk_reset_accum", "ptk_render", "ptk_render_static", "ptk_read_accum", "ptk_read_display_u8", "ptk_synchronize",
-           "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream"]
+           "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream",
+           "ptk_group_create", "ptk_group_destroy", "ptk_group_last_error", "ptk_group_size", "ptk_group_context",
+           "ptk_group_upload_scene", "ptk_group_set_camera", "ptk_group_set_flags", "ptk_group_reset_accum", "ptk_group_render",
+           "ptk_group_synchronize", "ptk_group_read_accum", "ptk_group_read_display_u8"]
+SPLITS = {"spp": 0, "tile": 1}  # PTK_SPLIT_SAMPLES, PTK_SPLIT_BANDS
 
 
 def make_scene_desc(sd):
@@ -194,6 +198,21 @@ def load_library():
     L.ptk_reset_stats.argtypes = [vp]
     L.ptk_stream.argtypes = [vp]
     L.ptk_stream.restype = vp
+    L.ptk_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.ptk_group_destroy.argtypes = [vp]
+    L.ptk_group_last_error.argtypes = [vp]
+    L.ptk_group_last_error.restype = C.c_char_p
+    L.ptk_group_size.argtypes = [vp]
+    L.ptk_group_context.argtypes = [vp, C.c_int]
+    L.ptk_group_context.restype = vp
+    L.ptk_group_upload_scene.argtypes = [vp, C.POINTER(PtkSceneDesc), C.c_int32]
+    L.ptk_group_set_camera.argtypes = [vp, C.POINTER(PtkCamera)]
+    L.ptk_group_set_flags.argtypes = [vp, C.POINTER(PtkFlags)]
+    L.ptk_group_reset_accum.argtypes = [vp]
+    L.ptk_group_render.argtypes = [vp, C.POINTER(PtkRenderParams), C.c_int32]
+    L.ptk_group_synchronize.argtypes = [vp]
+    L.ptk_group_read_accum.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    L.ptk_group_read_display_u8.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -300,3 +319,81 @@ class Context:
 
     def reset_stats(self):
         self._check(self._L.ptk_reset_stats(self.h), "ptk_reset_stats")
+
+
+class Group:
+    """One ptk_group: several GPUs behind one handle (one host thread, one RCCL reduce per frame read)."""
+
+    def __init__(self, devices):
+        self._L = load_library()
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self._L.ptk_group_create(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise PtkError(f"ptk_group_create failed ({rc}): {self._L.ptk_group_last_error(None).decode()}")
+        self.h = h
+        self.devices = devices
+        self.width = self.height = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtkError(f"{what} failed ({rc}): {self._L.ptk_group_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.ptk_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self._L.ptk_group_size(self.h))
+
+    def context_stats(self, index):
+        """ptk_get_stats of the index-th device's context."""
+        s = PtkStats()
+        c = C.c_void_p(self._L.ptk_group_context(self.h, int(index)))
+        rc = self._L.ptk_get_stats(c, C.byref(s))
+        if rc != 0:
+            raise PtkError(f"ptk_get_stats failed ({rc})")
+        return s.as_dict()
+
+    def upload_scene(self, sd, builder="host"):
+        desc, keep = make_scene_desc(sd)
+        self._check(self._L.ptk_group_upload_scene(self.h, C.byref(desc), BUILDERS[builder]), "ptk_group_upload_scene")
+        del keep
+
+    def set_camera(self, cd):
+        cam = cd if isinstance(cd, PtkCamera) else make_camera(cd)
+        self._check(self._L.ptk_group_set_camera(self.h, C.byref(cam)), "ptk_group_set_camera")
+        self.width, self.height = cam.width, cam.height
+
+    def set_flags(self, flags: PtkFlags):
+        self._check(self._L.ptk_group_set_flags(self.h, C.byref(flags)), "ptk_group_set_flags")
+
+    def reset_accum(self):
+        self._check(self._L.ptk_group_reset_accum(self.h), "ptk_group_reset_accum")
+
+    def render(self, samples, max_bounce, seed=1, sample_first=0, sample_stride=1, split="spp"):
+        p = PtkRenderParams(int(samples), int(max_bounce), int(seed), int(sample_first), int(sample_stride), 0, 0, 0, 0, 0, 1)
+        self._check(self._L.ptk_group_render(self.h, C.byref(p), SPLITS[split]), "ptk_group_render")
+
+    def synchronize(self):
+        self._check(self._L.ptk_group_synchronize(self.h), "ptk_group_synchronize")
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        total = C.c_int32(0)
+        self._check(self._L.ptk_group_read_accum(self.h, out.ctypes.data, C.byref(total)), "ptk_group_read_accum")
+        return out, int(total.value)
+
+    def read_display_u8(self):
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        total = C.c_int32(0)
+        self._check(self._L.ptk_group_read_display_u8(self.h, out.ctypes.data, C.byref(total)), "ptk_group_read_display_u8")
+        return out, int(total.value)

@@ -310,7 +310,8 @@ _CORNELL_QUADS = [
 
 
 def write_cornell_assets(directory, width=64, height=64, texture: Optional[np.ndarray] = None, spheres: bool = False,
-                         aperture: float = 0.5, focus_distance: float = 24.0) -> str:
+                         aperture: float = 0.5, focus_distance: float = 24.0, background_texture: Optional[str] = None,
+                         textured_sphere: Optional[str] = None) -> str:
     """Writes cornell_box.obj / .mtl / floor texture / config JSON into `directory`; returns the JSON path.
     The geometry, materials and camera equal cornell_box(width, height, texture=...)."""
     import json
@@ -353,6 +354,10 @@ def write_cornell_assets(directory, width=64, height=64, texture: Optional[np.nd
             {"center": {"x": -3, "y": 1.5, "z": -2.5}, "radius": 1.5, "type": "SPECULAR", "roughness": 0.0},
             {"hidden": True, "center": {"x": 0, "y": 8, "z": 0}, "radius": 1.5, "emissive": {"x": 2, "y": 2, "z": 2}},
         ]
+    if background_texture:  # wins over background_color (src/main.cpp:147-158)
+        cfg["background_texture"] = background_texture
+    if textured_sphere:
+        cfg.setdefault("spheres", []).append({"center": {"x": 0.5, "y": 1.2, "z": 1.5}, "radius": 1.2, "texture": textured_sphere})
     path = os.path.join(directory, "cornell_box.json")
     with open(path, "w") as f:
         json.dump(cfg, f, indent=1)

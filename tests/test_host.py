@@ -175,6 +175,40 @@ def test_pt_command_line_matches_oracle(tmp_path, with_spheres):
     assert subprocess.run([PT, str(tmp_path / "nope.json"), str(out)], capture_output=True).returncode == 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,split", [("0", "spp"), ("0,0", "tile"), ("0,0,0", "spp")])
+def test_pt_with_environment_map_file_and_textured_sphere(host, tmp_path, devices, split):
+    """The asset path end to end at the size of the reference's own environment map: a 3584 x 1792 baseline JPEG
+    (the reference's prater.jpg itself does not travel with the tests; this one is generated) decoded by the host
+    library, 19 MB of texels uploaded, sampled by the kernels as background; plus a sphere with a PNG texture
+    (JSON key spheres[].texture, src/main.cpp:75,135-142).  Also with the GPU named two and three times in
+    PT_DEVICES, so that the host API's multi-GPU path (ptk_group) runs on a one-GPU machine.  The oracle renders
+    the same scene from the texels the host decoder produced."""
+    from oracle import orc
+    env = scenes.procedural_envmap(3584, 1792)
+    Image.fromarray(np.flipud(env)).save(tmp_path / "sky.jpg", quality=90, subsampling=2)
+    globe = scenes.procedural_texture(256, 6, seed=3)
+    Image.fromarray(np.flipud(globe)).save(tmp_path / "globe.png")
+    cfg = scenes.write_cornell_assets(str(tmp_path), 80, 48, background_texture=str(tmp_path / "sky.jpg"),
+                                      textured_sphere=str(tmp_path / "globe.png"))
+    out = tmp_path / "result.png"
+    r = subprocess.run([PT, cfg, str(out), "24", "3", "8", "--seed", "9", "--split", split], capture_output=True, text=True,
+                       env=dict(os.environ, PT_DEVICES=devices), timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert "Loaded environment texture" in r.stdout and "Loaded texture" in r.stdout and "24/24 samples per pixel" in r.stdout
+    got = np.asarray(Image.open(out).convert("RGB")).astype(int)
+    decoded = _load(host, tmp_path / "sky.jpg")  # bottom-up rows, as the kernels and the oracle take them
+    assert decoded.shape == (1792, 3584, 3) and np.abs(decoded.astype(int) - env.astype(int)).mean() < 3.0
+    sd = scenes.cornell_box(80, 48)
+    tex = sd.add_texture(globe)
+    sd.add_sphere((0.5, 1.2, 1.5), 1.2, sd.add_material(scenes.Material(albedo=(1.0, 1.0, 1.0), texture=tex)))
+    sd.background_texture = sd.add_texture(decoded)
+    ref, _ = orc.OracleScene(sd).render(24, 3, seed=9)
+    d = np.abs(got - orc.tonemap_u8(ref).astype(int))
+    print(devices, split, "mean abs diff", d.mean())
+    assert d.mean() < 2.0
+
+
 def test_tree_cache_round_trip(tmp_path, monkeypatch):
     """PTK_BVH_CACHE: the second build of the same geometry reads the stored tree (same nodes, same hits); a
     damaged file is rejected by the validity check and rebuilt; other geometry gets its own file."""

@@ -7,6 +7,7 @@ Run once in a container where /root/reference exists; the outputs are committed.
   reference_render_top200.png  rows 0..199 of doc/results/render_d94b533_1024_3_25-11-2024_202142.png, the
                                reference's own 500x500 / 1024 spp / 3 bounce render of
                                assets/cornell_box/cornell_box.json (box + glass bunny + two spheres + env map)
+  reference_render_bottom60.png  rows 440..499 of the same render: the textured floor in front of the bunny and the spheres
   uv-test.png                  assets/textures/uv-test.png (the floor's map_Kd), unchanged
   prater_448x224.png           assets/textures/prater.jpg (the environment map) box-filtered 8x down
 """
@@ -21,6 +22,7 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 im = Image.open(os.path.join(REF, "doc/results/render_d94b533_1024_3_25-11-2024_202142.png")).convert("RGB")
 im.crop((0, 0, 500, 200)).save(os.path.join(OUT, "reference_render_top200.png"), optimize=True)
+im.crop((0, 440, 500, 500)).save(os.path.join(OUT, "reference_render_bottom60.png"), optimize=True)
 shutil.copyfile(os.path.join(REF, "assets/textures/uv-test.png"), os.path.join(OUT, "uv-test.png"))
 env = np.asarray(Image.open(os.path.join(REF, "assets/textures/prater.jpg")).convert("RGB"), np.float64)
 h, w, _ = env.shape

@@ -7,7 +7,8 @@ here:
   1. outputs of a reference run recorded when the reference was surveyed: the BVH it builds for the Cornell
      box and its own counters (bounce_counter, intersection_test_counter) on the CI configuration;
   2. the one render the reference repository publishes for assets/cornell_box/cornell_box.json
-     (doc/results/render_d94b533_1024_3_...png), compared where the missing bunny.obj does not matter;
+     (doc/results/render_d94b533_1024_3_...png), compared where the missing bunny.obj does not matter: all of
+     the picture above the bunny, and the textured floor in front of it;
   3. closed forms for every pure function, and moment tests for every sampler.
 """
 import ctypes as C
@@ -60,39 +61,85 @@ def test_cornell_counters_match_reference_run():
 
 
 # ------------------------------------------------------------------ 2. the reference's published render
-def test_published_render_top_rows():
-    """Rows 0..199 of the reference's published 500x500 render (ceiling, light, upper walls; the bunny, which is
-    not in the repository, starts below them).  That render predates the JSON's current camera_fov of 14.5: the
-    light's outline matches to the pixel at 14.0, so 14.0 is used.  Without the glass bunny a little more light
-    reaches the walls, so the oracle is allowed to be up to 6 levels (of 255) brighter, 3 darker."""
+# doc/results/render_d94b533_1024_3_25-11-2024_202142.png is the reference's own 500 x 500, 1024 spp, 3 bounce
+# render of assets/cornell_box/cornell_box.json: box, glass bunny, two spheres, environment map.  bunny.obj is not
+# in the repository, so only the parts of the picture that the bunny does not cover are compared: everything above
+# it (rows 0..199) and the floor in front of it (rows 440..499).  It is the only output of the reference that exists,
+# and it pins the camera model (the doubled image plane, the half-pixel shift), the light's place, the wall colours,
+# the display transform and the floor texture's orientation -- not hit ids.
+def _published_scene(fov):
     tex = np.flipud(np.asarray(Image.open(os.path.join(GOLDEN, "uv-test.png")).convert("RGB")))
     env = np.flipud(np.asarray(Image.open(os.path.join(GOLDEN, "prater_448x224.png")).convert("RGB")))
-    ref = np.asarray(Image.open(os.path.join(GOLDEN, "reference_render_top200.png")).convert("RGB")).astype(float)
     sd = scenes.cornell_box(500, 500, texture=tex)
     scenes.add_json_spheres(sd)
     sd.background_texture = sd.add_texture(env)
-    sd.camera.fov = 14.0
-    o = orc.OracleScene(sd)
-    buf, _ = o.render(32, 3, seed=3, rows=(0, 200))
+    sd.camera.fov = fov
+    return orc.OracleScene(sd)
+
+
+def _light_box(im):
+    m = im.min(axis=2) >= 250
+    m[150:, :] = False
+    ys, xs = np.nonzero(m)
+    return np.array([xs.min(), xs.max(), ys.min(), ys.max()])
+
+
+_PALETTE = np.array([[88, 140, 126], [242, 228, 148], [242, 174, 114], [217, 100, 89]], float)  # uv-test.png's four cell colours
+
+
+def _cell_colour(im):
+    """Index of the nearest of the floor texture's four cell colours (by chromaticity) and the distance to it."""
+    n = im / np.maximum(im.sum(axis=2, keepdims=True), 1.0)
+    p = _PALETTE / _PALETTE.sum(axis=1, keepdims=True)
+    d = ((n[:, :, None, :] - p[None, None]) ** 2).sum(-1)
+    return d.argmin(-1), d.min(-1)
+
+
+def test_published_render_was_made_with_fov_14():
+    """cornell_box.json says camera_fov 14.5 today; the published render predates that value.  With 14.0 the
+    light's outline falls on the published pixels (within one) and the floor's texture cells fall on the published
+    cells; with 14.5 the light sits 7 rows lower and fewer than half of the floor pixels land in the right cell.
+    Both numbers are printed, and the other tests on this picture use 14.0 for that reason."""
+    top = np.asarray(Image.open(os.path.join(GOLDEN, "reference_render_top200.png")).convert("RGB")).astype(float)
+    bottom = np.asarray(Image.open(os.path.join(GOLDEN, "reference_render_bottom60.png")).convert("RGB")).astype(float)
+    want_cell, want_dist = _cell_colour(bottom)
+    result = {}
+    for fov in (14.0, 14.5):
+        o = _published_scene(fov)
+        buf, _ = o.render(8, 3, seed=3, rows=(0, 150))
+        light = _light_box(orc.tonemap_u8(buf[:200]).astype(float))
+        buf, _ = o.render(96, 3, seed=3, rows=(440, 500))
+        got = orc.tonemap_u8(buf[440:500]).astype(float)
+        got_cell, got_dist = _cell_colour(got)
+        # floor pixels clear of the bunny, the spheres and their reflections, and clearly one of the four colours in both
+        clear = np.zeros_like(want_cell, bool)
+        clear[30:, 0:50] = True
+        clear[30:, 200:340] = True
+        clear &= (want_dist < 0.004) & (got_dist < 0.004) & (bottom.sum(axis=2) > 150) & (got.sum(axis=2) > 150)  # not the labels' strokes
+        agree = float((got_cell[clear] == want_cell[clear]).mean())
+        result[fov] = (np.abs(light - _light_box(top)).max(), agree, int(clear.sum()))
+        print("fov", fov, "light outline off by", result[fov][0], "px; floor cells agree on", round(agree, 3), "of", result[fov][2], "pixels")
+    assert result[14.0][0] <= 1 and result[14.0][1] >= 0.9 and result[14.0][2] > 1500
+    assert result[14.5][0] >= 5 and result[14.5][1] <= 0.6
+
+
+def test_published_render_everything_above_the_bunny():
+    """Rows 0..199 (ceiling, light, upper walls), every 20 x 20 block of it: the oracle's block means lie between the
+    published ones and 10 levels (of 255) above them.  Above, because the glass bunny, which the oracle's scene
+    lacks, keeps a little light from the walls; never below.  Mean absolute difference over the whole area < 6."""
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "reference_render_top200.png")).convert("RGB")).astype(float)
+    o = _published_scene(14.0)
+    buf, _ = o.render(48, 3, seed=3, rows=(0, 200))
     img = orc.tonemap_u8(buf[:200]).astype(float)
-
-    def light_box(im):
-        m = im.min(axis=2) >= 250
-        m[150:, :] = False
-        ys, xs = np.nonzero(m)
-        return xs.min(), xs.max(), ys.min(), ys.max()
-
-    assert np.max(np.abs(np.array(light_box(img)) - np.array(light_box(ref)))) <= 1
+    assert np.abs(_light_box(img) - _light_box(ref)).max() <= 1
     d = img - ref
-    regions = {"left wall": np.s_[0:200, 5:60], "right wall": np.s_[0:200, 440:495], "back wall": np.s_[100:200, 120:380]}
-    for name, sl in regions.items():
-        md = d[sl].mean(axis=(0, 1))
-        print(name, md)
-        assert (md < 6.0).all() and (md > -3.0).all(), (name, md)
+    blocks = d.reshape(10, 20, 25, 20, 3).mean(axis=(1, 3))
+    print("block mean differences: min", blocks.min(axis=(0, 1)), "max", blocks.max(axis=(0, 1)), "mean abs", np.abs(d).mean())
+    assert blocks.min() > -1.0 and blocks.max() < 10.0
+    assert np.abs(d).mean() < 6.0
     # the walls' own colours: red wall red, green wall green, as bright as the reference's
     assert abs(img[0:200, 5:60, 0].mean() - ref[0:200, 5:60, 0].mean()) < 6
     assert abs(img[0:200, 440:495, 1].mean() - ref[0:200, 440:495, 1].mean()) < 6
-    assert np.abs(d).mean() < 9.0
 
 
 # ------------------------------------------------------------------ 3. closed forms

@@ -115,7 +115,7 @@ typedef struct {
   int32_t sample_stride;  /* >= 1 */
   int32_t row_begin;      /* 0 */
   int32_t row_end;        /* <= 0 means height */
-  int32_t collect_stats;  /* 1: also count box / primitive tests (slower kernel variant) */
+  int32_t collect_stats;  /* 1: also count box / primitive tests (slower kernel variant; at most 2^20 samples per call) */
   int32_t band_rows;      /* 0: rows [row_begin, row_end); else a multiple of 8 */
   int32_t band_first;     /* >= 0 */
   int32_t band_stride;    /* >= 1 when band_rows > 0 */

@@ -180,22 +180,15 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   }
 }
 
-// The per-lane counts are 32-bit registers: a long launch empties them into the 64-bit totals whenever one
-// of them has passed 2^30 (checked where the wave hands out work items, i.e. at most a path's worth of
-// counting later), so they cannot wrap.  All 64 lanes must be active.
-__device__ __forceinline__ void flush_counters_if_large(Counters& c, unsigned long long* out)
-{
-  const uint32_t any = c.camera_rays | c.segments | c.queries | c.box_tests | c.prim_tests;
-  if (__ballot(any >= 0x40000000u) == 0ull) return;
-  flush_counters(c, out);
-  c = Counters{0, 0, 0, 0, 0};
-}
-
 template <bool STATS>
-__global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView sc, CameraView cam, FlagView fl, RenderArgs ra,
+__global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra,
                                                         f4* __restrict__ accum, f4* __restrict__ partial,
                                                         unsigned long long* counters)
 {
+  // read-only for the whole launch: the constant address space lets every use be a scalar load at that use
+  const auto* consts = (const __attribute__((address_space(4))) DeviceConsts*)consts_global;
+  const CameraView& cam = *(const CameraView*)&consts->cam;
+  const FlagView& fl = *(const FlagView*)&consts->fl;
   __shared__ uint32_t lds_stack[kStackDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
@@ -215,7 +208,7 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   pp.x0 = tx * kTile; pp.y0 = launch_row_to_image_row(ra, ty * kTile);
   pp.slot_bits = 6; pp.row_bits = 3;
   pp.x_end = cam.width; pp.y_end = ra.row_end;
-  pp.max_bounce = ra.max_bounce; pp.seed = ra.seed;
+  pp.max_bounce = ra.max_bounce; pp.seed = ra.seed; pp.camera_shift = consts->camera_shift;
   pp.samples = (ra.samples - chunk + ra.chunks - 1) / ra.chunks;  // chunk c takes samples c, c + chunks, ...
   pp.sample_first = ra.sample_first + chunk * ra.sample_stride;
   pp.sample_stride = ra.sample_stride * ra.chunks;
@@ -230,7 +223,6 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
   // Hand the next work items, in lane order, to the lanes that ask for one; repeat while a lane
   // was given an item that needs no query (a pixel slot outside the image).
   auto refill = [&](bool need) {
-    flush_counters_if_large(cnt, counters);
     for (;;) {
       unsigned long long m = __ballot(need);
       if (m == 0ull) break;
@@ -377,6 +369,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
   tr.node = kTravDone;
   tr.o = tr.d = V3(0.f, 0.f, 0.f);
   int32_t mine = -1;  // the ray this lane is working on
+  float shift = 0.0f; // how far its origin was advanced towards the scene (scene_entry_shift)
   int32_t held = kTravDone;
   bool alive = true;
   // Hit records leave through LDS.  A 52-byte record written by its own lane is thirteen 4-byte stores to
@@ -401,7 +394,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
         if (tr.hit.id != kNoPrim) {
           Surface s;
           make_surface(sc, tr.o, tr.d, tr.hit, s);
-          out.hit = 1; out.id = tr.hit.id; out.t = tr.hit.t;
+          out.hit = 1; out.id = tr.hit.id; out.t = tr.hit.t + shift;
           out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
           out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;
           out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
@@ -440,7 +433,9 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
           const float2 a = r[0], b = r[1], c = r[2];
           mine = (int32_t)take;
           cnt.queries++;
-          trav_begin(tr, st, sc, V3(a.x, a.y, b.x), V3(b.y, c.x, c.y), kTMax, kNoPrim);
+          const v3 o = V3(a.x, a.y, b.x), d = V3(b.y, c.x, c.y);
+          shift = scene_entry_shift(sc, o, d);
+          trav_begin(tr, st, sc, o + d * shift, d, kTMax, kNoPrim);
         } else {
           alive = false;
           mine = -1;
@@ -528,6 +523,7 @@ struct ptk_ctx {
   f4* d_partial = nullptr;  // per-chunk partial sums of the frame being rendered
   size_t partial_capacity = 0;  // in f4
   f4* d_static_scratch = nullptr;  // this device's copy of `scratch` (ptk_render_static)
+  DeviceConsts* d_consts = nullptr;  // camera, switches and camera shift as the render kernel reads them (sync_consts)
   // staging of ptk_intersect_batch's host arrays; kept between calls, so that a batch no larger than an earlier
   // one (a single ray of Scene::find_intersection, say) allocates nothing
   float* d_stage_rays = nullptr;
@@ -624,6 +620,24 @@ static int pick_chunks(int n_tiles, int samples)
   return (int)std::max<int64_t>(c, 1);
 }
 
+// Brings the device copy of the camera, the switches and the camera shift up to date (stream-ordered: launches
+// already queued keep the values they were queued with).
+static int sync_consts(ptk_ctx* ctx)
+{
+  DeviceConsts c;
+  std::memset(&c, 0, sizeof c);
+  c.cam = ctx->cam;
+  c.fl = ctx->flags;
+  if (ctx->have_scene && ctx->have_camera) {
+    SceneView bounds;  // the bounds' grid is all camera_entry_shift looks at (the view's pointers are device addresses)
+    std::memset(&bounds, 0, sizeof bounds);
+    bounds.grid = ctx->view.grid;
+    c.camera_shift = camera_entry_shift(bounds, ctx->cam);
+  }
+  PTK_HIP(hipMemcpyAsync(ctx->d_consts, &c, sizeof c, hipMemcpyHostToDevice, ctx->stream));
+  return PTK_OK;
+}
+
 static void release_host_copy(ptk_ctx* ctx)
 {
   std::vector<uint8_t>().swap(ctx->host.texels);
@@ -693,7 +707,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
   if (!keep_host) release_host_copy(ctx);  // the largest host copies are no longer needed
   ctx->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
-  return PTK_OK;
+  return sync_consts(ctx);
 }
 
 static int upload_scene_impl(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder, bool keep_host)
@@ -731,6 +745,7 @@ int ptk_create(int device, ptk_ctx** out)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, kCounterSlots * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_consts, sizeof(DeviceConsts));
   // with `device` current: the address of this device's copy of the static scratch array
   if (e == hipSuccess) e = hipGetSymbolAddress((void**)&ctx->d_static_scratch, HIP_SYMBOL(scratch));
   if (e != hipSuccess) {
@@ -754,6 +769,7 @@ int ptk_destroy(ptk_ctx* ctx)
   if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
   if (ctx->d_stage_hits) (void)hipFree(ctx->d_stage_hits);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_consts) (void)hipFree(ctx->d_consts);
   for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -823,14 +839,15 @@ int ptk_set_camera(ptk_ctx* ctx, const ptk_camera* camera)
   PTK_HIP(hipMemsetAsync(ctx->d_accum, 0, pixels * sizeof(f4), ctx->stream));
   ctx->cam = make_camera_view(*camera);
   ctx->have_camera = true;
-  return PTK_OK;
+  return sync_consts(ctx);
 }
 
 int ptk_set_flags(ptk_ctx* ctx, const ptk_flags* flags)
 {
   if (!ctx) return PTK_ERR_INVALID;
   ctx->flags = make_flag_view(flags);
-  return PTK_OK;
+  PTK_HIP(hipSetDevice(ctx->device));
+  return sync_consts(ctx);
 }
 
 int ptk_bind_accum(ptk_ctx* ctx, float* device_rgbw)
@@ -863,6 +880,9 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   if ((int64_t)p->sample_first + (int64_t)p->samples * p->sample_stride > (int64_t)INT32_MAX)
     return fail(ctx, PTK_ERR_LIMIT, "ptk_render: sample index exceeds 2^31 - 1");
   if (p->samples > (1 << 25)) return fail(ctx, PTK_ERR_LIMIT, "ptk_render: at most 2^25 samples per call");
+  // per-lane counts are 32-bit registers (summed over a wave in 64 bits): a lane's share of a launch that also
+  // counts box and primitive tests must stay below 2^32 of them
+  if (p->collect_stats && p->samples > (1 << 20)) return fail(ctx, PTK_ERR_LIMIT, "ptk_render: at most 2^20 samples per call with collect_stats");
   RenderArgs ra;
   ra.samples = p->samples; ra.seed = p->seed;
   ra.max_bounce = p->max_bounce < (1 << 23) ? p->max_bounce : (1 << 23);  // the range of the path state's depth field
@@ -916,11 +936,11 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
   if (p->collect_stats)
-    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
-                       partial, ctx->d_counters);
+    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial,
+                       ctx->d_counters);
   else
-    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->cam, ctx->flags, ra, ctx->d_accum,
-                       partial, ctx->d_counters);
+    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial,
+                       ctx->d_counters);
   PTK_HIP(hipGetLastError());
   if (static_scratch) ctx->launches++;
   else rc = end_timed(ctx, ev);

@@ -301,7 +301,28 @@ struct PathParams {
   int32_t x_end, y_end;          // slots at or beyond these pixel coordinates are outside the image
   int32_t samples, max_bounce, sample_first, sample_stride;
   uint32_t seed;
+  float camera_shift;            // camera_entry_shift() of the launch
 };
+
+// How far every camera ray of a launch can be advanced before it can meet the scene's bounds: the camera's
+// distance from them (less the lens radius, where ray origins are spread) when that is more than four times
+// the bounds' diagonal, otherwise 0.  Same reason as scene_entry_shift: box tests lose precision with the
+// origin's distance from the scene.  One number per launch, so it costs the kernel no registers.
+PTK_HD float camera_entry_shift(const SceneView& sc, const CameraView& cam)
+{
+  float dist2 = 0.0f, diag2 = 0.0f;
+  for (int a = 0; a < 3; a++) {
+    const float lo = sc.grid.origin[a], hi = sc.grid.origin[a] + 65535.0f * sc.grid.scale[a];
+    const float p = cam.position[a];
+    const float out = p < lo ? lo - p : (p > hi ? p - hi : 0.0f);
+    dist2 += out * out;
+    diag2 += (hi - lo) * (hi - lo);
+  }
+  const float lens = cam.defocus_radius * sqrtf(fmaxf(dot(ld3(cam.right), ld3(cam.right)), dot(ld3(cam.up), ld3(cam.up))));
+  const float dist = sqrtf(dist2) - lens, diag = sqrtf(diag2);
+  if (!(dist > 4.0f * diag)) return 0.0f;
+  return dist - fmaxf(0.5f * diag, dist * (1.0f / 1024.0f));
+}
 
 struct SumAccum {  // accumulator of a one-pixel tile
   v3 sum;
@@ -345,7 +366,8 @@ PTK_HD bool path_begin_item(PathState& ps, Stack& st, const SceneView& sc, const
   ps.beta = V3(1.0f, 1.0f, 1.0f);
   cnt.segments++;
   cnt.queries++;
-  trav_begin(ps.tr, st, sc, o, d, kTMax, kNoPrim);
+  // a camera far outside the scene: start the traversal in front of the scene's bounds (camera_entry_shift; d is a unit vector)
+  trav_begin(ps.tr, st, sc, o + d * pp.camera_shift, d, kTMax, kNoPrim);
   return false;
 }
 
@@ -527,6 +549,7 @@ PTK_HD v3 render_pixel(const SceneView& sc, const CameraView& cam, const FlagVie
   pp.x_end = px + 1; pp.y_end = py + 1;
   pp.samples = samples; pp.max_bounce = max_bounce; pp.sample_first = sample_first; pp.sample_stride = sample_stride;
   pp.seed = seed;
+  pp.camera_shift = camera_entry_shift(sc, cam);
   PathState ps;
   path_init(ps);
   SumAccum acc;

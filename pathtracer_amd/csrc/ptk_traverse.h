@@ -163,6 +163,32 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
   tr.node = sc.n_prims > 0 ? 0 : kTravDone;
 }
 
+// How far a ray that starts far outside the scene can be advanced before it meets the scene's bounds.
+// hit_box evaluates plane distances as differences of numbers that grow with the origin's distance from the
+// scene, so their rounding grows with that distance while the padding of the boxes does not: from more than about
+// thirty scene extents away a thin box could be missed.  Camera rays and the rays of the batch entry point
+// (the only ones that can start outside the bounds) are therefore moved to half a chord in front of the bounds
+// whenever the origin is farther from them than twice the ray's chord through them; hit distances are then
+// measured from the moved origin and this distance is added back.  0 for every other ray.  (The render kernel
+// does the same for camera rays with one distance per launch: camera_entry_shift.)
+PTK_HD float scene_entry_shift(const SceneView& sc, v3 o, v3 d)
+{
+  const float big = 1e20f;
+  const v3 rd = V3(fmaxf(fminf(frcp(d.x), big), -big), fmaxf(fminf(frcp(d.y), big), -big), fmaxf(fminf(frcp(d.z), big), -big));
+  const v3 lo = V3((sc.grid.origin[0] - o.x) * rd.x, (sc.grid.origin[1] - o.y) * rd.y, (sc.grid.origin[2] - o.z) * rd.z);
+  const v3 hi = V3((sc.grid.origin[0] + 65535.0f * sc.grid.scale[0] - o.x) * rd.x,
+                   (sc.grid.origin[1] + 65535.0f * sc.grid.scale[1] - o.y) * rd.y,
+                   (sc.grid.origin[2] + 65535.0f * sc.grid.scale[2] - o.z) * rd.z);
+  const float tn = fmaxf(fmaxf(fminf(lo.x, hi.x), fminf(lo.y, hi.y)), fminf(lo.z, hi.z));
+  const float tf = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fmaxf(lo.z, hi.z));
+  const float chord = tf - tn;
+  if (!(chord > 0.0f) || !(tn > 2.0f * chord) || !(tn < 1e18f)) return 0.0f;  // misses, near origins, NaN
+  // stay clear of the bounds: by half a chord, and by enough that the "t >= 1e-5" rule, which is now applied
+  // from the moved origin, cannot reject anything inside them (a flat scene's chord is next to nothing)
+  const float shift = tn - 0.5f * chord - fmaxf(tn * (1.0f / 1024.0f), 2e-4f);
+  return shift > 0.0f ? shift : 0.0f;
+}
+
 // Experiment hook (-DPTK_BURN_*): twelve extra vector instructions, to weigh a code region's share of the
 // kernel's time by how much slower it gets.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -286,12 +312,14 @@ PTK_HD bool closest_hit(const SceneView& sc, v3 o, v3 d, float tmax, uint32_t sk
                         Counters& cnt)
 {
   Traversal tr;
-  trav_begin(tr, st, sc, o, d, tmax, skip_id);
+  const float shift = scene_entry_shift(sc, o, d);
+  trav_begin(tr, st, sc, o + d * shift, d, tmax, skip_id);
   while (!trav_done(tr)) {
     if (trav_at_inner(tr)) trav_inner<Stack, STATS>(tr, st, sc, cnt);
     else trav_leaf<Stack, STATS>(tr, st, sc, cnt);
   }
   hit = tr.hit;
+  hit.t += shift;
   return hit.id != kNoPrim;
 }
 

@@ -188,6 +188,9 @@ def load_library():
     L.ptk_bind_accum.argtypes = [vp, vp]
     L.ptk_reset_accum.argtypes = [vp]
     L.ptk_render.argtypes = [vp, C.POINTER(PtkRenderParams)]
+    if os.environ.get("PTK_LIB") and not hasattr(L, "ptk_group_create"):
+        _lib = L  # an older build of the library selected for an A/B run: only the entry points it has
+        return L
     L.ptk_render_static.argtypes = [vp, C.POINTER(PtkRenderParams)]
     L.ptk_read_accum.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.ptk_read_display_u8.argtypes = [vp, vp, C.POINTER(C.c_int32)]

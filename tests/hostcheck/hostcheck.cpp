@@ -141,7 +141,11 @@ int hc_intersect(void* h, const ptk_ray* rays, int n, ptk_hit* hits, uint64_t* c
     cnt.box_tests = cnt.prim_tests = 0;
     if (closest_hit<HostStack, true>(sc, o, d, kTMax, kNoPrim, st, hit, cnt)) {
       Surface s;
-      make_surface(sc, o, d, hit, s);
+      // the hit point is formed from the origin the traversal used (moved towards a far-away scene), as the kernel forms it
+      const float shift = scene_entry_shift(sc, o, d);
+      Hit moved = hit;
+      moved.t = hit.t - shift;
+      make_surface(sc, o + d * shift, d, moved, s);
       out.hit = 1; out.id = hit.id; out.t = hit.t;
       out.point[0] = s.point.x; out.point[1] = s.point.y; out.point[2] = s.point.z;
       out.normal[0] = s.normal.x; out.normal[1] = s.normal.y; out.normal[2] = s.normal.z;

@@ -46,7 +46,10 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 #define PTK_ITEM_MIN 8      // hand out work items once this many lanes are free
 #endif
 #ifndef PTK_MIN_WAVES
-#define PTK_MIN_WAVES 5     // __launch_bounds__ waves per SIMD for the render kernel: 96 VGPRs, 6 of them spilled
+#define PTK_MIN_WAVES 5     // __launch_bounds__ waves per SIMD of the render kernel's deep-tree form: 96 VGPRs
+#endif
+#ifndef PTK_MIN_WAVES_SHALLOW
+#define PTK_MIN_WAVES_SHALLOW 6  // ... and of its shallow-tree form: 80 VGPRs (6 of them spilled), 6400 bytes of LDS
 #endif
 // A frame whose tiles alone give the chip only a few rounds of waves ends with most CUs idle
 // while the slowest tiles finish, so a tile's samples are split over several workgroups.
@@ -85,11 +88,13 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
 #endif
+template <int DEPTH>
 struct LdsStack {
+  static constexpr int kDepth = DEPTH;
   static constexpr int kStep = PTK_STACK_LANE_MAJOR ? 1 : kBlock;  // words between a lane's consecutive entries
   uint32_t* top;   // this lane's top entry
   uint32_t* base;  // this lane's entry 0
-  __device__ __forceinline__ void attach(uint32_t* array, int lane) { base = top = array + (PTK_STACK_LANE_MAJOR ? lane * kStackDepth : lane); }
+  __device__ __forceinline__ void attach(uint32_t* array, int lane) { base = top = array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane); }
   __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
   __device__ __forceinline__ void push(uint32_t v) { top += kStep; *top = v; }
   __device__ __forceinline__ uint32_t pop() { uint32_t v = *top; top -= kStep; return v; }
@@ -180,16 +185,18 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra,
-                                                        f4* __restrict__ accum, f4* __restrict__ partial,
-                                                        unsigned long long* counters)
+// DEEP: the scene's tree has more than kShallowTreeDepth levels (see ptk_layout.h: stack size, LDS, waves per SIMD)
+template <bool STATS, bool DEEP>
+__global__ __launch_bounds__(kBlock, DEEP ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
+    SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra, f4* __restrict__ accum, f4* __restrict__ partial,
+    unsigned long long* counters)
 {
+  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : kStackDepthShallow>;
   // read-only for the whole launch: the constant address space lets every use be a scalar load at that use
   const auto* consts = (const __attribute__((address_space(4))) DeviceConsts*)consts_global;
   const CameraView& cam = *(const CameraView*)&consts->cam;
   const FlagView& fl = *(const FlagView*)&consts->fl;
-  __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
   st.attach(lds_stack, (int)threadIdx.x);
@@ -222,6 +229,12 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
 
   // Hand the next work items, in lane order, to the lanes that ask for one; repeat while a lane
   // was given an item that needs no query (a pixel slot outside the image).
+  // Path segments and queries started by this wave, counted for the whole wave at once where its phases end
+  // (a ballot and a scalar add) instead of in a register of every lane: the per-lane counts of `cnt` are left
+  // unread in this kernel, so the compiler drops them.  Camera rays are counted by the host (rows x width x samples).
+  // (The deep-tree form has the registers and is 1 % faster with the per-lane counts, so it keeps them.)
+  constexpr bool kWaveCounts = !DEEP;
+  unsigned long long wave_segments = 0, wave_queries = 0;
   auto refill = [&](bool need) {
     for (;;) {
       unsigned long long m = __ballot(need);
@@ -229,7 +242,13 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       uint32_t item = next_item + rank;
       next_item += (uint32_t)__popcll(m);
+      const bool asked = need;
       if (need) need = path_begin_item(ps, st, sc, cam, pp, item, cnt);
+      if (kWaveCounts) {
+        const unsigned long long began = (unsigned long long)__popcll(__ballot(asked && !need && ps.alive));  // a primary ray is on its way
+        wave_segments += began;
+        wave_queries += began;
+      }
     }
   };
   refill(true);
@@ -280,12 +299,29 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
     const bool idle = __ballot(!done) == 0ull;  // no lane is traversing: everything that waits must run now
     if (idle && n_lit + n_shade + __popcll(__ballot(need)) == 0) break;
     if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
-      if (lit && path_consume_shadow(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
+      bool goes_on = false;
+      if (lit) {
+        goes_on = !path_consume_shadow(ps, st, sc, fl, pp, cnt);
+        if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
+      }
+      if (kWaveCounts) {
+        const unsigned long long began = (unsigned long long)__popcll(__ballot(goes_on));  // the path's next segment
+        wave_segments += began;
+        wave_queries += began;
+      }
     }
     PTK_PHASE_CLOCK(2)
     if (n_shade >= PTK_SHADE_MIN || (idle && n_shade > 0)) {
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
-      if (shade && path_shade(ps, st, sc, fl, pp, cnt)) { acc.add(ps.slot(), ps.L); need = true; }
+      bool goes_on = false;
+      if (shade) {
+        goes_on = !path_shade(ps, st, sc, fl, pp, cnt);
+        if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
+      }
+      if (kWaveCounts) {
+        wave_queries += (unsigned long long)__popcll(__ballot(goes_on));                 // a shadow ray or the next segment
+        wave_segments += (unsigned long long)__popcll(__ballot(goes_on && !ps.shadow));  // the next segment
+      }
     }
     PTK_PHASE_CLOCK(3)
     const int n_need = __popcll(__ballot(need));
@@ -316,7 +352,15 @@ __global__ __launch_bounds__(kBlock, PTK_MIN_WAVES) void render_kernel(SceneView
       partial[i] = a;
     }
   }
-  flush_counters(cnt, counters);
+  {
+    const unsigned long long boxes = STATS ? wave_sum(cnt.box_tests) : 0ull, prims = STATS ? wave_sum(cnt.prim_tests) : 0ull;
+    if (!kWaveCounts) { wave_segments = wave_sum(cnt.segments); wave_queries = wave_sum(cnt.queries); }
+    if (lane == 0) {
+      atomicAdd(&counters[1], wave_segments);
+      atomicAdd(&counters[2], wave_queries);
+      if (STATS) { atomicAdd(&counters[3], boxes); atomicAdd(&counters[4], prims); }
+    }
+  }
 }
 
 // accum[rows of the launch] += partial[0] + partial[1] + ... in that order (one fixed summation
@@ -344,11 +388,12 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(f4* __restrict__ acc
 #ifndef PTK_INTERSECT_WAVES
 #define PTK_INTERSECT_WAVES 1
 #endif
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
                                                            ptk_hit* __restrict__ hits, unsigned long long* counters)
 {
-  __shared__ uint32_t lds_stack[kStackDepth * kBlock];
+  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : kStackDepthShallow>;
+  __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ uint32_t lds_finished[kBlock];  // the lanes whose records wait to be written out, in rank order
 #ifdef PTK_INTERSECT_LDS_PAD
   __shared__ uint32_t lds_pad[PTK_INTERSECT_LDS_PAD / 4];
@@ -377,7 +422,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
   // stack region, and the whole wave then copies the finished records out with consecutive lanes writing
   // consecutive words, so that a store instruction covers whole records.
   constexpr uint32_t kRecordWords = sizeof(ptk_hit) / 4;
-  static_assert(sizeof(ptk_hit) % 4 == 0 && kRecordWords + 2 <= (uint32_t)kStackDepth && PTK_STACK_LANE_MAJOR,
+  static_assert(sizeof(ptk_hit) % 4 == 0 && kRecordWords + 2 <= (uint32_t)kStackDepthShallow && PTK_STACK_LANE_MAJOR,
                 "a hit record and its ray index must fit a lane's stack region above the sentinel");
   for (;;) {
     const bool done = trav_done(tr);
@@ -414,7 +459,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
         uint32_t* out_words = reinterpret_cast<uint32_t*>(hits);
         for (uint32_t i = lane; i < total; i += kBlock) {
           const uint32_t r = i / kRecordWords, k = i - r * kRecordWords;
-          const uint32_t* rec = lds_stack + lds_finished[r] * (uint32_t)kStackDepth + 1;
+          const uint32_t* rec = lds_stack + lds_finished[r] * (uint32_t)LdsStack::kDepth + 1;
 #ifndef PTK_EXP_NO_HIT_OUTPUT
           out_words[(size_t)rec[kRecordWords] * kRecordWords + k] = rec[k];
 #else
@@ -500,6 +545,7 @@ struct ptk_ctx {
   std::string err;
   // scene
   bool have_scene = false;
+  bool deep_tree = true;         // the tree has more than kShallowTreeDepth levels: the kernels' deep form runs
   bool have_scene_host = false;  // `host` still holds everything another context would need (ctx_upload_like)
   int32_t builder_asked = 0;
   HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
@@ -534,6 +580,7 @@ struct ptk_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
   double ms_last = 0.0, ms_total = 0.0;
   uint64_t launches = 0;
+  uint64_t camera_rays = 0;  // of the render launches since ptk_reset_stats: rows x width x samples, counted here
 };
 
 static std::string g_create_error;
@@ -607,9 +654,9 @@ static int upload(ptk_ctx* ctx, void** dst, const std::vector<T>& src)
 // ends with most CUs idle while the slowest tiles finish; splitting every tile's samples over
 // several workgroups shortens that tail.  Each chunk keeps at least kMinChunkSamples samples so
 // that a lane still has work to refill with when its neighbours' paths end.
-static int pick_chunks(int n_tiles, int samples)
+static int pick_chunks(int n_tiles, int samples, int waves_per_simd)
 {
-  constexpr int64_t kResidentWaves = 256 * 4 * PTK_MIN_WAVES;
+  const int64_t kResidentWaves = 256 * 4 * waves_per_simd;
   constexpr int64_t kRounds = PTK_CHUNK_ROUNDS;
   constexpr int kMinChunkSamples = PTK_CHUNK_MIN_SAMPLES;
   int64_t waves = (int64_t)n_tiles;
@@ -682,6 +729,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
     free_scene(ctx);
     return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
   }
+  ctx->deep_tree = h.max_depth > kShallowTreeDepth || getenv("PTK_FORCE_DEEP") != nullptr;
   if (!on_device) {
     if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
     if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
@@ -908,7 +956,7 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int tiles_y = (launch_rows + kTile - 1) / kTile;
   ra.rows = tiles_y * kTile;
   ra.n_tiles = ra.tiles_x * tiles_y;
-  ra.chunks = pick_chunks(ra.n_tiles, p->samples);
+  ra.chunks = pick_chunks(ra.n_tiles, p->samples, ctx->deep_tree ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
   PTK_HIP(hipSetDevice(ctx->device));
   size_t band_pixels = (size_t)ra.rows * (size_t)ctx->cam.width;
   f4* partial = ctx->d_partial;
@@ -931,16 +979,18 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
     }
     partial = ctx->d_partial;
   }
+  {  // camera rays of this launch: every pixel of every row it covers, `samples` times (none when nothing may bounce: still counted, as Camera::get_ray is still called)
+    uint64_t rows = 0;
+    for (int r = 0; r < launch_rows; r++) rows += launch_row_to_image_row(ra, r) < ra.row_end ? 1u : 0u;
+    ctx->camera_rays += rows * (uint64_t)ctx->cam.width * (uint64_t)p->samples;
+  }
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
-  if (p->collect_stats)
-    hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial,
-                       ctx->d_counters);
-  else
-    hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial,
-                       ctx->d_counters);
+  auto kernel = ctx->deep_tree ? (p->collect_stats ? render_kernel<true, true> : render_kernel<false, true>)
+                               : (p->collect_stats ? render_kernel<true, false> : render_kernel<false, false>);
+  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters);
   PTK_HIP(hipGetLastError());
   if (static_scratch) ctx->launches++;
   else rc = end_timed(ctx, ev);
@@ -1021,8 +1071,9 @@ static int launch_intersect(ptk_ctx* ctx, const float* d_rays, int32_t n, ptk_hi
   int rc = begin_timed(ctx, ev);
   if (rc) return rc;
   dim3 grid((unsigned)std::min<int64_t>(((int64_t)n + kBlock - 1) / kBlock, 16384)), block(kBlock);  // 4 rounds of the resident waves
-  if (stats) hipLaunchKernelGGL(intersect_kernel<true>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
-  else hipLaunchKernelGGL(intersect_kernel<false>, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
+  auto kernel = ctx->deep_tree ? (stats ? intersect_kernel<true, true> : intersect_kernel<false, true>)
+                               : (stats ? intersect_kernel<true, false> : intersect_kernel<false, false>);
+  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
   PTK_HIP(hipGetLastError());
   return end_timed(ctx, ev);
 }
@@ -1077,7 +1128,7 @@ int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
   if (rc) return rc;
   unsigned long long c[kCounterSlots];
   PTK_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-  out->camera_rays = c[0]; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
+  out->camera_rays = ctx->camera_rays; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
   PTK_PHASE(if (getenv("PTK_PHASE_STATS")) {
     auto pct = [](unsigned long long lanes, unsigned long long iters) { return iters ? 100.0 * (double)lanes / (64.0 * (double)iters) : 0.0; };
     fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes\n",
@@ -1100,6 +1151,7 @@ int ptk_reset_stats(ptk_ctx* ctx)
   PTK_HIP(hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream));
   ctx->ms_last = ctx->ms_total = 0.0;
   ctx->launches = 0;
+  ctx->camera_rays = 0;
   return PTK_OK;
 }
 

@@ -11,14 +11,22 @@ namespace ptk {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
-// Per-lane traversal stack entries: a sentinel, one per tree level, one of scratch.  27 entries x 64 lanes
-// x 4 bytes + the tile's pixel sums = 7680 bytes of LDS per wave, which lets 20 waves (5 per SIMD) share a
-// CU's 160 KB; 28 entries no longer do (measured: 5 waves +8 %, and back to the 4-wave rate at 28).
+// Per-lane traversal stack entries: a sentinel, one per tree level, one of scratch.  LDS is handed out in
+// granules of 1280 bytes and a one-wave workgroup also keeps its tile's pixel sums (768 bytes) there, so the
+// stack decides how many waves a CU's 160 KB can hold:
+//   deep    27 entries x 64 lanes x 4 bytes + sums = 7680 bytes = 6 granules: 20 waves per CU, 5 per SIMD;
+//           trees up to 25 levels (28 entries no longer fit: measured, back to the 4-wave rate)
+//   shallow 22 entries + sums = 6400 bytes = 5 granules: 24 waves per CU, 6 per SIMD (the kernel is then built
+//           for 80 vector registers instead of 96); trees up to 20 levels.  The sixth wave is worth 5-11 % on
+//           the 82k-triangle scenes; capping the 1.3M-triangle scene's tree at 20 levels to get it costs 12 %.
+// The kernels exist in both forms and the scene's tree depth picks one.
 #ifndef PTK_STACK_DEPTH
 #define PTK_STACK_DEPTH 27
 #endif
-constexpr int kStackDepth = PTK_STACK_DEPTH;
+constexpr int kStackDepth = PTK_STACK_DEPTH;   // deep form: the largest stack
+constexpr int kStackDepthShallow = 22;
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
+constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
 
 // Inner node with the boxes of BOTH children, 32 bytes: two 16-byte fetches per lane decide both.  The
 // render kernel is bound by the number of cache accesses a wave makes (every lane is at its own node, so each

@@ -398,7 +398,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   if (sc.n_lights == 0) return false;
   int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
   if (idx > sc.n_lights - 1) idx = sc.n_lights - 1;
-  const LightRec light = sc.lights[idx];
+  const LightRec& light = sc.lights[idx];  // by reference: fields are fetched where they are used, not all 28 words at once
   float r1 = rnd(ps.g), r2 = rnd(ps.g);
   v3 q, normal;
   if (light.kind == kTriangle) {  // Primitive::sample_point, src/geometry.cpp:228-241
@@ -468,7 +468,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   }
   Surface s;
   make_surface(sc, o, d, ps.tr.hit, s);
-  const MaterialRec m = sc.materials[s.material];
+  const MaterialRec& m = sc.materials[s.material];
   if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
     ps.L += ps.beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
     return true;

@@ -413,6 +413,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     r.width = t.width; r.height = t.height;
     size_t bytes = (size_t)t.width * (size_t)t.height * 3;
     out.texels.insert(out.texels.end(), t.rgb, t.rgb + bytes);
+    out.texels.push_back(0);  // the kernels fetch a texel as one 4-byte word: a byte beyond the last texel must exist
     while (out.texels.size() % 16) out.texels.push_back(0);
     out.textures.push_back(r);
   }

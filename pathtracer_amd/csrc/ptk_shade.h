@@ -108,7 +108,15 @@ PTK_HD Texel texel(const SceneView& sc, const TextureRec& t, int x, int y)
   Texel p = {1, 0, 1};
   if (x < 0 || x >= t.width || y < 0 || y >= t.height) return p;
   const uint8_t* q = sc.texels + t.offset + ((size_t)y * (size_t)t.width + (size_t)x) * 3;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one 4-byte fetch instead of three 1-byte ones (the texel pool ends in padding, so the fourth byte exists;
+  // global memory takes unaligned 4-byte loads)
+  struct __attribute__((packed)) Word { uint32_t v; };
+  const uint32_t w = reinterpret_cast<const Word*>(q)->v;
+  p.r = (int)(w & 0xffu); p.g = (int)((w >> 8) & 0xffu); p.b = (int)((w >> 16) & 0xffu);
+#else
   p.r = q[0]; p.g = q[1]; p.b = q[2];
+#endif
   return p;
 }
 

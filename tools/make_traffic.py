@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
-"""Turn the FETCH_SIZE / WRITE_SIZE counters of a tools/profile.sh summary into the per-launch HBM traffic
-figure that bench.py reports as roofline.traffic.
+"""Turn the counters of a tools/profile.sh summary into the per-launch figures that bench.py reports under
+"roofline" (traffic, l2_hit_rate, valu_lane_utilisation, valu_issue_slots_used, wait_fraction).
 
     tools/make_traffic.py <summary.json> <workload_WxH_SPPspp> [traffic.json]
 
-rocprofv3 gives both counters in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes,
-so reads are doubled (the correction measured for wide coalesced reads; the 64-byte node and 48-byte triangle
-gathers of this kernel are not separately calibrated, which makes the figure an upper bound)."""
+rocprofv3 gives FETCH_SIZE / WRITE_SIZE in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-byte requests as
+64 bytes, so reads are doubled (the correction measured for wide coalesced reads; the 32-byte node and 40-byte
+triangle gathers of this kernel are not separately calibrated, which makes the figure an upper bound).
+SQ cycle counters are in units of four cycles and summed over all waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
 import json, sys
 
 summary, key = json.load(open(sys.argv[1])), sys.argv[2]
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
-per = [v for k, v in summary["counters_per_dispatch"].items() if "Lb0E" in k or "<false>" in k][0]
-ms = [v for k, v in summary.get("kernel_ms", {}).items() if "render_kernel<false>" in k or "Lb0E" in k]
+per = [v for k, v in summary["counters_per_dispatch"].items() if "render_kernel<false" in k][0]
+ms = [v for k, v in summary.get("kernel_ms", {}).items() if "render_kernel<false" in k]
 read_b, write_b = per["FETCH_SIZE"] * 1024.0 * 2.0, per["WRITE_SIZE"] * 1024.0
 try:
     out = json.load(open(path))
 except Exception:
     out = {}
+kernel_cycles = per["GRBM_GUI_ACTIVE"] / 8.0
 out[key] = {"hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b,
             "fetch_size_kib_raw": per["FETCH_SIZE"], "write_size_kib_raw": per["WRITE_SIZE"],
             "l2_hit_rate": per["TCC_HIT_sum"] / max(1.0, per["TCC_HIT_sum"] + per["TCC_MISS_sum"]),
+            "l1_hit_rate": 1.0 - per["TCP_TCC_READ_REQ_sum"] / max(1.0, per["TCP_TOTAL_CACHE_ACCESSES_sum"]),
+            "valu_lane_utilisation": per["SQ_THREAD_CYCLES_VALU"] / max(1.0, 64.0 * per["SQ_ACTIVE_INST_VALU"]),
+            "valu_issue_slots_used": per["SQ_INSTS_VALU"] * 2.0 / (1024.0 * kernel_cycles),
+            "wait_fraction": per["SQ_WAIT_ANY"] / per["SQ_WAVE_CYCLES"],
+            "issue_stall_fraction": per["SQ_WAIT_INST_ANY"] / per["SQ_WAVE_CYCLES"],
+            "clock_ghz": kernel_cycles / (ms[0]["avg_ms"] * 1e-3) / 1e9 if ms else None,
+            "valu_instructions": per["SQ_INSTS_VALU"], "salu_instructions": per["SQ_INSTS_SALU"],
+            "vmem_read_instructions": per["SQ_INSTS_VMEM_RD"], "l1_accesses": per["TCP_TOTAL_CACHE_ACCESSES_sum"],
             "kernel_ms_rocprof": ms[0]["avg_ms"] if ms else None, "source": summary.get("dir")}
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[key]))

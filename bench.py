@@ -179,8 +179,16 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
     if rank != 0:
         return None
 
-    bytes_per_ray = box_per_ray * 32.0 + prim_per_ray * 36.0 + 48.0
-    flops_per_ray = box_per_ray * 21.0 + prim_per_ray * 60.0 + 250.0 * seg_per_ray
+    cpu = cpu_baseline(sd, spp, bounces, args.cpu_seconds) if with_cpu else None
+    # Work is counted per ray as the smaller of what this tree and the reference's tree need: a test that the
+    # reference would not have made is not algorithmic work (only the 5-node Cornell box does more box tests here,
+    # because a node visit tests both children; the reference's counts come from the CPU leg, when it ran).
+    box_counted, prim_counted = box_per_ray, prim_per_ray
+    if cpu:
+        box_counted = min(box_per_ray, cpu["box_tests_per_ray"])
+        prim_counted = min(prim_per_ray, cpu["prim_tests_per_ray"])
+    bytes_per_ray = box_counted * 32.0 + prim_counted * 36.0 + 48.0
+    flops_per_ray = box_counted * 21.0 + prim_counted * 60.0 + 250.0 * seg_per_ray
     rays_per_launch = st["queries"] / max(1, st["launches"])
     kernel_s = (st["kernel_ms_total"] / max(1, st["launches"])) / 1e3
     achieved_tf = rays_per_launch * flops_per_ray / kernel_s / 1e12
@@ -192,14 +200,16 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
     roofline = {"bound": "fp32_valu", "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac,
                 "traffic": traffic, "hbm_frac": hbm_frac, "kernel": "render_kernel", "kernel_ms_avg": kernel_s * 1e3,
                 "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray, "box_tests_per_ray": box_per_ray,
-                "prim_tests_per_ray": prim_per_ray, "rays_per_launch": rays_per_launch,
+                "prim_tests_per_ray": prim_per_ray, "box_tests_counted": box_counted, "prim_tests_counted": prim_counted,
+                "rays_per_launch": rays_per_launch,
                 "algorithmic_gbs": algorithmic_gbs, "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
-                "l2_hit_rate": tr.get("l2_hit_rate") if tr else None,
-                "valu_lane_utilisation": tr.get("valu_lane_utilisation") if tr else None,
-                "valu_issue_slots_used": tr.get("valu_issue_slots_used") if tr else None,
-                "wait_fraction": tr.get("wait_fraction") if tr else None,
                 "note": "scene is cache resident: algorithmic bytes are served by L1/L2, HBM traffic is a few percent of "
-                        "its peak, so the fp32 vector rate is the bound reported; counters from profiles/"}
+                        "its peak, so the fp32 vector rate is the bound reported; 'units' holds the hardware counters of "
+                        "the same launch from profiles/ (busy fractions of the vector ALU, the L1's address and data units)"}
+    if tr:
+        roofline["units"] = {k: tr.get(k) for k in ("l1_hit_rate", "l2_hit_rate", "valu_lane_utilisation", "valu_fast_share",
+                                                    "valu_pipe_occupancy_lower", "valu_pipe_occupancy_upper", "ta_busy", "td_busy",
+                                                    "l1_latency_cycles", "wait_fraction") if tr.get(k) is not None}
     if hbm_frac is not None and hbm_frac > valu_frac:
         roofline.update({"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac})
     out = {
@@ -215,8 +225,8 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
         "rays_per_segment": queries / max(1.0, segments),
         "roofline": roofline,
     }
-    if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(sd, spp, bounces, args.cpu_seconds)
+    if cpu:
+        out["cpu_baseline"] = cpu
     return out
 
 

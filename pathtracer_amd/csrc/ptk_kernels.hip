@@ -331,8 +331,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLO
     }
     PTK_PHASE_CLOCK(4)
   }
+  PTK_PHASE(ph[7] = (uint32_t)wave_sum(cnt.leaf_iterations);)
   PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) {
-    for (int k = 0; k < 7; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);
+    for (int k = 0; k < 8; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);
     for (int k = 0; k < 5; k++) atomicAdd(&counters[16 + k], tph[k]);
   })
   __syncthreads();
@@ -1131,8 +1132,9 @@ int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
   out->camera_rays = ctx->camera_rays; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
   PTK_PHASE(if (getenv("PTK_PHASE_STATS")) {
     auto pct = [](unsigned long long lanes, unsigned long long iters) { return iters ? 100.0 * (double)lanes / (64.0 * (double)iters) : 0.0; };
-    fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes\n",
-            c[8], pct(c[9], c[8]), c[10], pct(c[11], c[10]), pct(c[12], c[10]), c[13], pct(c[14], c[13]));
+    fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes | leaf-loop passes: %llu (%.2f per leaf phase), %.1f%% lanes\n",
+            c[8], pct(c[9], c[8]), c[10], pct(c[11], c[10]), pct(c[12], c[10]), c[13], pct(c[14], c[13]), c[15], c[10] ? (double)c[15] / c[10] : 0.0,
+            pct(c[4], c[15]));
     const double tsum = (double)(c[16] + c[17] + c[18] + c[19] + c[20]);
     if (tsum > 0)
       fprintf(stderr, "[ptk phase clocks] descend %.1f%% (%.0f per wave-step) | leaves %.1f%% (%.0f) | lit %.1f%% | shade %.1f%% (%.0f per shade step) | refill %.1f%%\n",

@@ -28,19 +28,20 @@ constexpr int kStackDepthShallow = 22;
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
 
-// Inner node with the boxes of BOTH children, 32 bytes: two 16-byte fetches per lane decide both.  The
-// render kernel is bound by the number of cache accesses a wave makes (every lane is at its own node, so each
-// 16-byte load is one access per lane), which is why the boxes are not stored as floats: box planes are
-// 16-bit positions on a grid over the scene's bounds (BoxGrid), rounded outwards, low plane in the low half
-// of a word and high plane in the high half.
+// Inner node with the boxes of BOTH children, 32 bytes.  The render kernel is bound by the number of bytes its
+// lanes pull through the L1 (every lane is at its own node), which is why the boxes are not stored as floats:
+// box planes are 16-bit positions on a grid over the scene's bounds (BoxGrid), rounded outwards, low plane in
+// the low half of a word and high plane in the high half.  The words of one axis sit next to each other, child
+// 0 first, so that one typed 8-byte load (four 16-bit integers -> four floats, converted by the memory pipeline)
+// brings an axis of both boxes: three such loads and one 8-byte load of the links per visit.
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first_prim << 3) | (count - 1).
 struct alignas(16) NodePair {
-  uint32_t x0, y0, z0;  // child 0
-  uint32_t x1;          // child 1
-  uint32_t y1, z1;
+  uint32_t x0, x1;  // x planes of child 0, of child 1
+  uint32_t y0, y1;
+  uint32_t z0, z1;
   int32_t child0, child1;
 };
-static_assert(sizeof(NodePair) == 32, "NodePair must be two 16-byte fetches");
+static_assert(sizeof(NodePair) == 32, "NodePair is 32 bytes");
 
 // plane position = origin + q * scale for q in 0 .. 65535, per axis
 struct BoxGrid {
@@ -186,6 +187,9 @@ struct DeviceConsts {
 
 struct Counters {
   uint32_t camera_rays, segments, queries, box_tests, prim_tests;
+#ifdef PTK_PHASE_STATS
+  uint32_t leaf_iterations = 0;  // passes of a leaf loop, counted once per wave (by the first active lane)
+#endif
 };
 
 }  // namespace ptk

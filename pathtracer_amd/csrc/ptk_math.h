@@ -81,6 +81,20 @@ PTK_HD void sincos_turns(float turns, float* s, float* c)
 #endif
 }
 
+// One 16-byte fetch of a record's chunk.  On the device it is written as a vector load, which the compiler
+// keeps as ONE instruction (a struct copy is taken apart into single words and only sometimes put together
+// again; each separate load costs the memory pipeline what a 16-byte one does).
+PTK_HD f4 load16(const void* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  const vf4 v = *reinterpret_cast<const vf4*>(p);
+  return f4{v.x, v.y, v.z, v.w};
+#else
+  return *reinterpret_cast<const f4*>(p);
+#endif
+}
+
 PTK_HD float as_float(uint32_t u)
 {
   union { uint32_t u; float f; } c;

@@ -96,22 +96,66 @@ PTK_HD float min_raw(float a, float b)
 #endif
 }
 
-// Slab test of one child box against [0, tbest]; returns entry distance in tn.  wx, wy, wz: the box's grid
-// words (low plane | high plane << 16).  The ray carries inv = grid scale / d and oi = (o - grid origin) / d
-// per axis, so the distance to grid plane q is fma(q, inv, -oi): one conversion and one fma per plane.
-// fminf/fmaxf drop NaNs, and the caller keeps 1/d finite (axis-parallel rays get +-1e20), so a slab the
-// origin lies in gives -huge..+huge and a slab it lies outside gives two huge values of one sign.  The
-// rounding of these products is covered by the padding the builder puts on every box.
-PTK_HD bool hit_box(uint32_t wx, uint32_t wy, uint32_t wz, v3 oi, v3 inv, float tbest, float& tn)
+// Slab test of one child box against [0, tbest]; returns the entry distance in tn.  (lo, hi): the box's grid
+// planes per axis, as floats.  The ray carries inv = grid scale / d and oi = (o - grid origin) / d per axis, so
+// the distance to grid plane q is fma(q, inv, -oi).  Which of an axis' two planes is the near one depends on
+// the sign of d only, so the ray also carries inv split by sign (neg = min(inv, 0), pos = max(inv, 0)) and the
+// two distances are
+//     near = t(lo) + (hi - lo) * neg,   far = t(lo) + (hi - lo) * pos
+// - a subtraction and three fused multiply-adds per axis, all of which issue at the full vector rate on this
+// hardware (v_min_f32 / v_max_f32 take twice as long as v_fma_f32: see tools/ubench/valu_rate.hip).
+// The caller keeps 1/d finite (axis-parallel rays get +-1e20), so a slab the origin lies in gives -huge..+huge
+// and a slab it lies outside gives two huge values of one sign.  The rounding of these products is covered by
+// the padding the builder puts on every box.
+struct RaySlabs {
+  v3 inv, oi, neg, pos;
+};
+PTK_HD RaySlabs ray_slabs(v3 inv, v3 oi)
 {
-  float tx0 = fmaf((float)(wx & 0xffffu), inv.x, -oi.x), tx1 = fmaf((float)(wx >> 16), inv.x, -oi.x);
-  float ty0 = fmaf((float)(wy & 0xffffu), inv.y, -oi.y), ty1 = fmaf((float)(wy >> 16), inv.y, -oi.y);
-  float tz0 = fmaf((float)(wz & 0xffffu), inv.z, -oi.z), tz1 = fmaf((float)(wz >> 16), inv.z, -oi.z);
-  float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-  float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), min_raw(fmaxf(tz0, tz1), tbest));
+  RaySlabs r;
+  r.inv = inv; r.oi = oi;
+  r.neg = V3(fminf(inv.x, 0.0f), fminf(inv.y, 0.0f), fminf(inv.z, 0.0f));
+  r.pos = V3(inv.x - r.neg.x, inv.y - r.neg.y, inv.z - r.neg.z);
+  return r;
+}
+PTK_HD bool hit_box(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, const RaySlabs& r, float tbest, float& tn)
+{
+  const float tx = fmaf(xlo, r.inv.x, -r.oi.x), ex = xhi - xlo;
+  const float ty = fmaf(ylo, r.inv.y, -r.oi.y), ey = yhi - ylo;
+  const float tz = fmaf(zlo, r.inv.z, -r.oi.z), ez = zhi - zlo;
+  const float nx = fmaf(ex, r.neg.x, tx), fx = fmaf(ex, r.pos.x, tx);
+  const float ny = fmaf(ey, r.neg.y, ty), fy = fmaf(ey, r.pos.y, ty);
+  const float nz = fmaf(ez, r.neg.z, tz), fz = fmaf(ez, r.pos.z, tz);
+  const float tnear = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+  const float tfar = fminf(fminf(fx, fy), min_raw(fz, tbest));
   tn = tnear;
   return tnear <= tfar;  // no slack needed: the builder pads every box well beyond the rounding of these products
 }
+
+// Experiment (-DPTK_TYPED_NODE_LOADS=1): fetch a node's boxes with three typed loads, which saves the twelve
+// conversions of a visit but makes it four memory instructions instead of two: measured 2-8 % slower.
+#ifndef PTK_TYPED_NODE_LOADS
+#define PTK_TYPED_NODE_LOADS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Typed buffer load: 8 bytes holding four 16-bit unsigned integers arrive as four floats (the conversion is
+// done by the memory pipeline, exactly; measured to cost what a plain 8-byte load costs).
+typedef int ptk_v4i __attribute__((ext_vector_type(4)));
+typedef float ptk_v4f __attribute__((ext_vector_type(4)));
+__device__ ptk_v4f ptk_buffer_load_format_xyzw(ptk_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
+// Buffer resource over `bytes` bytes at `base`: no stride (offsets are bytes), destination select x, y, z, w,
+// number format USCALED (2), data format 16_16_16_16 (12).
+__device__ __forceinline__ ptk_v4i node_box_resource(const void* base, uint32_t bytes)
+{
+  const uint64_t a = (uint64_t)base;
+  ptk_v4i r;
+  r.x = (int)(uint32_t)a;
+  r.y = (int)(uint32_t)((a >> 32) & 0xffffu);
+  r.z = (int)bytes;
+  r.w = (int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (2u << 12) | (12u << 15));
+  return r;
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // Resumable traversal.  A lane's query is a small state (ray, closest hit so far, current
@@ -207,13 +251,26 @@ template <class Stack, bool STATS>
 PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
 {
   // a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address arithmetic
-  // (loaded whole, by value: the child links must not become a second, dependent fetch)
-  const NodePair n = *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) +
-                                                         ((uint32_t)tr.node * (uint32_t)sizeof(NodePair)));
+  const uint32_t node_off = (uint32_t)tr.node * (uint32_t)sizeof(NodePair);
+  const char* node_at = reinterpret_cast<const char*>(sc.nodes) + node_off;
+#if defined(__HIP_DEVICE_COMPILE__) && PTK_TYPED_NODE_LOADS
+  const ptk_v4i boxes = node_box_resource(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sizeof(NodePair));
+  const ptk_v4f bx = ptk_buffer_load_format_xyzw(boxes, (int)node_off, 0, 0);  // lo0, hi0, lo1, hi1
+  const ptk_v4f by = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 8, 0, 0);
+  const ptk_v4f bz = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 16, 0, 0);
+  const int32_t child0 = *reinterpret_cast<const int32_t*>(node_at + 24), child1 = *reinterpret_cast<const int32_t*>(node_at + 28);
+#else
+  const NodePair nd = *reinterpret_cast<const NodePair*>(node_at);  // loaded whole, by value: two 16-byte fetches
+  struct { float x, y, z, w; } bx, by, bz;
+  bx.x = (float)(nd.x0 & 0xffffu); bx.y = (float)(nd.x0 >> 16); bx.z = (float)(nd.x1 & 0xffffu); bx.w = (float)(nd.x1 >> 16);
+  by.x = (float)(nd.y0 & 0xffffu); by.y = (float)(nd.y0 >> 16); by.z = (float)(nd.y1 & 0xffffu); by.w = (float)(nd.y1 >> 16);
+  bz.x = (float)(nd.z0 & 0xffffu); bz.y = (float)(nd.z0 >> 16); bz.z = (float)(nd.z1 & 0xffffu); bz.w = (float)(nd.z1 >> 16);
+  const int32_t child0 = nd.child0, child1 = nd.child1;
+#endif
 #ifdef PTK_EXTRA_LOAD  // experiment: one more 16-byte cache access per node visit, result unused
   {
     // 1: at the lane's own node; 2: lanes 2k and 2k+1 read the two adjacent halves of lane 2k's node
-    uint32_t off = (uint32_t)tr.node * (uint32_t)sizeof(NodePair);
+    uint32_t off = node_off;
 #if PTK_EXTRA_LOAD == 2 && defined(__HIP_DEVICE_COMPILE__)
     const uint32_t partner = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
     const bool odd = (threadIdx.x & 1u) != 0;
@@ -238,14 +295,15 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   }
 #endif
   float tn0, tn1;
-  bool h0 = hit_box(n.x0, n.y0, n.z0, tr.oi, tr.inv, tr.hit.t, tn0);
-  bool h1 = hit_box(n.x1, n.y1, n.z1, tr.oi, tr.inv, tr.hit.t, tn1);
+  const RaySlabs rs = ray_slabs(tr.inv, tr.oi);  // does not change between a query's visits
+  bool h0 = hit_box(bx.x, bx.y, by.x, by.y, bz.x, bz.y, rs, tr.hit.t, tn0);
+  bool h1 = hit_box(bx.z, bx.w, by.z, by.w, bz.z, bz.w, rs, tr.hit.t, tn1);
   if (STATS) cnt.box_tests += 2;
   // logical operators on purpose: the results stay lane masks (scalar and/or) instead of 0/1 integers
   const bool both = h0 && h1, none = !h0 && !h1;
   const bool closer1 = tn1 < tn0;
   const bool first1 = h1 && (!h0 || closer1);  // child 1 is the one to visit first
-  const int32_t near = first1 ? n.child1 : n.child0, far = first1 ? n.child0 : n.child1;
+  const int32_t near = first1 ? child1 : child0, far = first1 ? child0 : child1;
   const uint32_t top = st.step(both, (uint32_t)far, none);
   tr.node = none ? (int32_t)top : near;
 }
@@ -285,14 +343,31 @@ PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Co
   const uint32_t leaf = ~(uint32_t)node;
   const uint32_t count = (leaf & 7u) + 1u;
   uint32_t off = (leaf >> 3) * (uint32_t)sizeof(PrimRec);
-  // the next record is fetched while this one is tested
-  PrimRec p = load_prim(sc, off);
-  for (uint32_t i = 0; i < count; i++) {
-    PrimRec next = p;
-    off += (uint32_t)sizeof(PrimRec);
-    if (i + 1 < count) next = load_prim(sc, off);
-    trav_test_prim<STATS>(tr, p, cnt);
-    p = next;
+  // The next record is fetched while this one is tested.  Two records take turns (the loop is unrolled by two)
+  // so that "next becomes current" is not ten register moves per primitive.
+  PrimRec p0 = load_prim(sc, off), p1 = p0;
+  for (uint32_t i = 0;; i += 2) {
+#if defined(PTK_PHASE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    {
+      const unsigned long long active = __ballot(true);
+      if (__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u)) == 0u) cnt.leaf_iterations++;
+    }
+#endif
+    const bool second = i + 1 < count;
+    if (second) p1 = load_prim(sc, off + (uint32_t)sizeof(PrimRec));
+    trav_test_prim<STATS>(tr, p0, cnt);
+    if (!second) break;
+    const bool third = i + 2 < count;
+    off += 2u * (uint32_t)sizeof(PrimRec);
+    if (third) p0 = load_prim(sc, off);
+#if defined(PTK_PHASE_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    {
+      const unsigned long long active = __ballot(true);
+      if (__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u)) == 0u) cnt.leaf_iterations++;
+    }
+#endif
+    trav_test_prim<STATS>(tr, p1, cnt);
+    if (!third) break;
   }
   return (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);
 }

@@ -32,5 +32,18 @@ out[key] = {"hbm_bytes_per_launch": read_b + write_b, "read_bytes": read_b, "wri
             "valu_instructions": per["SQ_INSTS_VALU"], "salu_instructions": per["SQ_INSTS_SALU"],
             "vmem_read_instructions": per["SQ_INSTS_VMEM_RD"], "l1_accesses": per["TCP_TOTAL_CACHE_ACCESSES_sum"],
             "kernel_ms_rocprof": ms[0]["avg_ms"] if ms else None, "source": summary.get("dir")}
+# passes of tools/profile_mem.sh / profile_mix.sh, when they were merged into the same directory
+if "TA_TA_BUSY_sum" in per:
+    out[key].update({"ta_busy": per["TA_TA_BUSY_sum"] / (256.0 * kernel_cycles), "td_busy": per["TD_TD_BUSY_sum"] / (256.0 * kernel_cycles),
+                     "l1_latency_cycles": per["TCP_TCP_LATENCY_sum"] / max(1.0, per["TCP_TA_TCP_STATE_READ_sum"]),
+                     "l1_pending_stall": per["TCP_PENDING_STALL_CYCLES_sum"] / (256.0 * kernel_cycles)})
+if "SQ_INSTS_VALU_FMA_F32" in per:
+    fast = per["SQ_INSTS_VALU_FMA_F32"] + per["SQ_INSTS_VALU_MUL_F32"] + per["SQ_INSTS_VALU_ADD_F32"]
+    trans = per["SQ_INSTS_VALU_TRANS_F32"]
+    rest = per["SQ_INSTS_VALU"] - fast - trans
+    # measured issue cost per wave64 instruction (tools/ubench/valu_rate.hip): fma/mul/add 2 cycles, transcendentals 8,
+    # everything else 4 at most (moves, and/or/xor and integer adds are 2: they cannot be told apart here, so this is an upper bound)
+    out[key].update({"valu_fast_share": fast / per["SQ_INSTS_VALU"], "valu_pipe_occupancy_upper": (2.0 * fast + 4.0 * rest + 8.0 * trans) / (1024.0 * kernel_cycles),
+                     "valu_pipe_occupancy_lower": 2.0 * per["SQ_INSTS_VALU"] / (1024.0 * kernel_cycles)})
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[key]))

@@ -3,9 +3,8 @@
 // One lane per path.  A one-wave workgroup renders an 8x8 pixel tile (or one chunk of its
 // samples): the tile's (pixel, sample) pairs are a pool of work items that the wave's 64 lanes
 // draw from, so the primary rays of a refill are neighbours and no lane idles while another
-// still has samples to do.  The traversal stack lives in LDS, strided by lane
-// (stack[level][lane]) so that all 64 lanes of a push or pop touch different banks; the tile's
-// pixel sums live in LDS too.  Workgroup ids are remapped so that the workgroups that share an
+// still has samples to do.  The traversal stack lives in LDS, a lane's entries next to each
+// other (stack[lane][level], see LdsStack); the tile's pixel sums live in LDS too.  Workgroup ids are remapped so that the workgroups that share an
 // XCD (and its L2) render the chunks of one tile, then the neighbouring tile, and so that every
 // XCD gets an equal share of every part of the image.
 #include <hip/hip_runtime.h>
@@ -32,7 +31,7 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 // Wave scheduling knobs of the render kernel (see its main loop).  Measured on the 81,920-triangle
 // mesh scene (1024x1024, 1024 spp, 3 bounces), each against the values below: descend 8: -8%,
 // 12: -2%, 20: -1%, 24: -3%; lit 4: same, 16: -1%; shade 16: -1%, 32: -1%; item 4: -1%, 16: -3%;
-// 4 waves per SIMD (109 VGPRs, none spilled): -8%, 6 (80 VGPRs, 22-entry stack): -12%.
+// 4 waves per SIMD (109 VGPRs, none spilled): -8%.  Swept again for the 6-wave form: the same values stay best.
 #ifndef PTK_DESCEND_MIN
 #define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
 #endif

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ptk.h"
@@ -184,13 +185,37 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   }
 }
 
-// DEEP: the scene's tree has more than kShallowTreeDepth levels (see ptk_layout.h: stack size, LDS, waves per SIMD)
-template <bool STATS, bool DEEP>
-__global__ __launch_bounds__(kBlock, DEEP ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
+// The kernel's forms (see ptk_layout.h: stack size, LDS, waves per SIMD): kFormShallow for trees of at most
+// kShallowTreeDepth levels, kFormDeep for deeper ones, kFormTiny for scenes whose whole tree and primitive records
+// fit a few KB of LDS (traversed from there).
+constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2;
+template <bool STATS, int FORM>
+__global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
     SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra, f4* __restrict__ accum, f4* __restrict__ partial,
     unsigned long long* counters)
 {
-  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : kStackDepthShallow>;
+  constexpr bool DEEP = FORM == kFormDeep, TINY = FORM == kFormTiny;
+  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : (TINY ? kStackDepthTiny : kStackDepthShallow)>;
+  using Mem = typename std::conditional<TINY, LdsMem, GlobalMem>::type;
+  constexpr int kSceneChunks = (kTinyNodes * sizeof(NodePair) + kTinyPrims * (sizeof(PrimRec) + sizeof(ShadeRec)) +
+                                kTinyMaterials * sizeof(MaterialRec) + kTinyLights * sizeof(LightRec)) / sizeof(f4);
+  __shared__ f4 lds_scene[TINY ? kSceneChunks : 1];
+  Mem mem;
+  if constexpr (TINY) {
+    // the workgroup's own copy of the scene, all of it but the texels (the __syncthreads below covers it)
+    f4* at = lds_scene;
+    auto take = [&](const void* from, int records, int chunks_per_record, int capacity) {
+      f4* to = at;
+      for (int i = (int)threadIdx.x; i < records * chunks_per_record; i += kBlock) to[i] = reinterpret_cast<const f4*>(from)[i];
+      at += capacity * chunks_per_record;
+      return to;
+    };
+    mem.nodes = (const PTK_LDS_SPACE char*)take(sc.nodes, sc.n_nodes, sizeof(NodePair) / sizeof(f4), kTinyNodes);
+    mem.prims = (const PTK_LDS_SPACE char*)take(sc.prims, sc.n_prims, sizeof(PrimRec) / sizeof(f4), kTinyPrims);
+    mem.shades = (const PTK_LDS_SPACE ShadeRec*)take(sc.shade, sc.n_prims, sizeof(ShadeRec) / sizeof(f4), kTinyPrims);
+    mem.materials = (const PTK_LDS_SPACE MaterialRec*)take(sc.materials, sc.n_materials, sizeof(MaterialRec) / sizeof(f4), kTinyMaterials);
+    mem.lights = (const PTK_LDS_SPACE LightRec*)take(sc.lights, sc.n_lights, sizeof(LightRec) / sizeof(f4), kTinyLights);
+  }
   // read-only for the whole launch: the constant address space lets every use be a scalar load at that use
   const auto* consts = (const __attribute__((address_space(4))) DeviceConsts*)consts_global;
   const CameraView& cam = *(const CameraView*)&consts->cam;
@@ -281,15 +306,15 @@ __global__ __launch_bounds__(kBlock, DEEP ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLO
       const bool any_held = __ballot(held != kTravDone) != 0ull;
       if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
-      if (want) trav_inner<LdsStack, STATS>(ps.tr, st, sc, cnt);
+      if (want) trav_inner<LdsStack, STATS, Mem>(ps.tr, st, sc, cnt, mem);
     }
     PTK_PHASE_CLOCK(0)
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
     if (held != kTravDone) {
-      if (trav_leaf_prims<STATS>(ps.tr, held, sc, cnt)) ps.tr.node = kTravDone;
+      if (trav_leaf_prims<STATS, Mem>(ps.tr, held, sc, cnt, mem)) ps.tr.node = kTravDone;
       held = kTravDone;
     }
-    if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS>(ps.tr, st, sc, cnt);
+    if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS, Mem>(ps.tr, st, sc, cnt, mem);
     PTK_PHASE_CLOCK(1)
     const bool done = trav_done(ps.tr);
     const bool waiting = ps.alive && done && !need;
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLO
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
       bool goes_on = false;
       if (shade) {
-        goes_on = !path_shade(ps, st, sc, fl, pp, cnt);
+        goes_on = !path_shade<LdsStack, Mem>(ps, st, sc, fl, pp, cnt, mem);
         if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
       }
       if (kWaveCounts) {
@@ -546,6 +571,7 @@ struct ptk_ctx {
   // scene
   bool have_scene = false;
   bool deep_tree = true;         // the tree has more than kShallowTreeDepth levels: the kernels' deep form runs
+  bool tiny_scene = false;       // the tree and the primitive records fit the render kernel's LDS copy: its tiny form runs
   bool have_scene_host = false;  // `host` still holds everything another context would need (ctx_upload_like)
   int32_t builder_asked = 0;
   HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
@@ -730,6 +756,9 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
     return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
   }
   ctx->deep_tree = h.max_depth > kShallowTreeDepth || getenv("PTK_FORCE_DEEP") != nullptr;
+  ctx->tiny_scene = !ctx->deep_tree && h.max_depth <= kTinyTreeDepth && ctx->n_nodes <= kTinyNodes && h.n_prims <= kTinyPrims && h.n_prims > 0 &&
+                    (int)h.materials.size() <= kTinyMaterials && (int)h.lights.size() <= kTinyLights &&
+                    getenv("PTK_NO_TINY") == nullptr;
   if (!on_device) {
     if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
     if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
@@ -988,8 +1017,9 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
-  auto kernel = ctx->deep_tree ? (p->collect_stats ? render_kernel<true, true> : render_kernel<false, true>)
-                               : (p->collect_stats ? render_kernel<true, false> : render_kernel<false, false>);
+  auto kernel = ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
+                : ctx->tiny_scene ? (p->collect_stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>)
+                                  : (p->collect_stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>);
   hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters);
   PTK_HIP(hipGetLastError());
   if (static_scratch) ctx->launches++;

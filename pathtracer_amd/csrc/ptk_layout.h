@@ -27,6 +27,12 @@ constexpr int kStackDepth = PTK_STACK_DEPTH;   // deep form: the largest stack
 constexpr int kStackDepthShallow = 22;
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
+// Tiny scenes (the Cornell box: 5 nodes, 12 triangles, 6 materials, 2 lights): the render kernel has a third form
+// that copies the whole scene except the texels into LDS when a workgroup starts and works from there - no
+// vector-memory instruction in the traversal, and none in shading but the texture fetches.  16 nodes (512 B) + 24
+// primitive records (1 152) + 24 shading records (1 536) + 8 materials (384) + 4 lights (448) + 6-entry stacks
+// (1 536) + sums (768) = 6 336 bytes, inside the five LDS granules of the six-wave forms.
+constexpr int kTinyNodes = 16, kTinyPrims = 24, kTinyMaterials = 8, kTinyLights = 4, kStackDepthTiny = 6, kTinyTreeDepth = kStackDepthTiny - 2;
 
 // Inner node with the boxes of BOTH children, 32 bytes.  The render kernel is bound by the number of bytes its
 // lanes pull through the L1 (every lane is at its own node), which is why the boxes are not stored as floats:

@@ -50,7 +50,8 @@ PTK_HD float rnd(Rng& r)
 }
 
 // ---------------------------------------------------------------- small helpers
-PTK_HD v3 ld3(const float* p) { return V3(p[0], p[1], p[2]); }
+template <class P>
+PTK_HD v3 ld3(P p) { return V3(p[0], p[1], p[2]); }  // P: pointer to three floats, in global memory or LDS
 
 // util.h:83-89 (y is the polar axis)
 PTK_HD v3 spherical_dir(float cos_theta, float sin_theta, float phi_turns)
@@ -161,7 +162,8 @@ PTK_HD v3 background(const SceneView& sc, v3 dir)
 }
 
 // Intersection::albedo, src/geometry.cpp:18-26
-PTK_HD v3 surface_albedo(const SceneView& sc, const MaterialRec& m, const Surface& s)
+template <class M>
+PTK_HD v3 surface_albedo(const SceneView& sc, const M& m, const Surface& s)
 {
   if (m.texture >= 0) return pow3(sample_texture(sc, m.texture, s.uv[0], s.uv[1]), 2.2f);
   return ld3(m.albedo);
@@ -205,7 +207,8 @@ PTK_HD float schlick_reflectance(float cosine, float ri)
 
 // BxDF::sample, src/material.cpp:110-122.  Draw order: dielectric takes one uniform (the
 // reflect/refract choice), every other type two (direction).
-PTK_HD v3 bsdf_sample(const FlagView& fl, const MaterialRec& m, bool inside, v3 wo, Rng& g)
+template <class M>
+PTK_HD v3 bsdf_sample(const FlagView& fl, const M& m, bool inside, v3 wo, Rng& g)
 {
   if (m.type == 4u /* DIELECTRIC, :225-240 */) {
     float r = rnd(g);
@@ -234,7 +237,8 @@ PTK_HD v3 bsdf_sample(const FlagView& fl, const MaterialRec& m, bool inside, v3 
 }
 
 // BxDF::eval, src/material.cpp:124-136
-PTK_HD v3 bsdf_eval(const FlagView& fl, const MaterialRec& m, v3 albedo, v3 V, v3 L)
+template <class M>
+PTK_HD v3 bsdf_eval(const FlagView& fl, const M& m, v3 albedo, v3 V, v3 L)
 {
   if (m.type == 4u) return V3(1.0f, 1.0f, 1.0f);  // :242
   if (m.type == 16u) {                            // :175-215
@@ -399,14 +403,15 @@ PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, con
 // frame, no cosine at the shading point and no 1/pi -- all as the reference does it.  Everything except
 // the visibility query is evaluated here; the result waits in ps.pending until the shadow ray returns.
 // Returns false when no shadow ray is needed.
-PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const MaterialRec& m, const Surface& s,
+template <class M, class Mem>
+PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const M& m, const Surface& s,
                       v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out, float& t_stop_out,
-                      uint32_t& light_id_out)
+                      uint32_t& light_id_out, const Mem& mem)
 {
   if (sc.n_lights == 0) return false;
   int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
   if (idx > sc.n_lights - 1) idx = sc.n_lights - 1;
-  const LightRec& light = sc.lights[idx];  // by reference: fields are fetched where they are used, not all 28 words at once
+  const auto& light = mem.light(sc, idx);  // by reference: fields are fetched where they are used, not all 28 words at once
   float r1 = rnd(ps.g), r2 = rnd(ps.g);
   v3 q, normal;
   if (light.kind == kTriangle) {  // Primitive::sample_point, src/geometry.cpp:228-241
@@ -462,9 +467,9 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
 }
 
 // A path segment's query has finished: shade the vertex it found.  Returns true when the path ends here.
-template <class Stack>
+template <class Stack, class Mem = GlobalMem>
 PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
-                       Counters& cnt)
+                       Counters& cnt, const Mem& mem = Mem())
 {
   const v3 o = ps.tr.o, d = ps.tr.d;
 #ifdef PTK_BURN_SHADE
@@ -475,8 +480,8 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     return true;
   }
   Surface s;
-  make_surface(sc, o, d, ps.tr.hit, s);
-  const MaterialRec& m = sc.materials[s.material];
+  make_surface(sc, o, d, ps.tr.hit, s, mem);
+  const auto& m = mem.material(sc, s.material);
   if (fl.debug_normal) {  // normal_as_color, src/renderer.cpp:17,74-76
     ps.L += ps.beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
     return true;
@@ -506,7 +511,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   float distance, t_stop;
   uint32_t light_id;
   if (fl.direct_light_sampling && !specular &&
-      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id)) {
+      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id, mem)) {
     ps.shadow = true;
     ps.next_d = next_d;
     cnt.queries++;

@@ -244,23 +244,59 @@ PTK_HD float scene_entry_shift(const SceneView& sc, v3 o, v3 d)
 #define PTK_BURN12(x) (void)(x)
 #endif
 
+// Where a traversal step fetches nodes and primitive records from: global memory, or (scenes of a few dozen
+// primitives) the copy that the workgroup made in LDS when it started.  Offsets are bytes from the array's start.
+struct GlobalMem {
+  PTK_HD NodePair node(const SceneView& sc, uint32_t off) const
+  {
+    return *reinterpret_cast<const NodePair*>(reinterpret_cast<const char*>(sc.nodes) + off);  // loaded whole, by value: two 16-byte fetches
+  }
+  PTK_HD PrimRec prim(const SceneView& sc, uint32_t off) const
+  {
+    return *reinterpret_cast<const PrimRec*>(reinterpret_cast<const char*>(sc.prims) + off);
+  }
+  // shading-side tables: by reference, fields are fetched where they are used
+  PTK_HD const ShadeRec& shade(const SceneView& sc, uint32_t id) const { return sc.shade[id]; }
+  PTK_HD const MaterialRec& material(const SceneView& sc, uint32_t i) const { return sc.materials[i]; }
+  PTK_HD const LightRec& light(const SceneView& sc, int i) const { return sc.lights[i]; }
+};
+#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTK_LDS_SPACE __attribute__((address_space(3)))  // the loads must be ds_read, not flat loads
+#else
+#define PTK_LDS_SPACE  // the host pass only has to parse the kernels
+#endif
+struct LdsMem {
+  const PTK_LDS_SPACE char* nodes;
+  const PTK_LDS_SPACE char* prims;
+  const PTK_LDS_SPACE ShadeRec* shades;
+  const PTK_LDS_SPACE MaterialRec* materials;
+  const PTK_LDS_SPACE LightRec* lights;
+  PTK_HD NodePair node(const SceneView&, uint32_t off) const { return *reinterpret_cast<const PTK_LDS_SPACE NodePair*>(nodes + off); }
+  PTK_HD PrimRec prim(const SceneView&, uint32_t off) const { return *reinterpret_cast<const PTK_LDS_SPACE PrimRec*>(prims + off); }
+  PTK_HD const PTK_LDS_SPACE ShadeRec& shade(const SceneView&, uint32_t id) const { return shades[id]; }
+  PTK_HD const PTK_LDS_SPACE MaterialRec& material(const SceneView&, uint32_t i) const { return materials[i]; }
+  PTK_HD const PTK_LDS_SPACE LightRec& light(const SceneView&, int i) const { return lights[i]; }
+};
+#endif
+
 // Visit one inner node.  Straight-line code: whether a child is pushed, and whether the next node
 // comes from the stack, are decided by selects, and the stack is touched the same way every time
 // (Stack::step reads the top entry, writes the candidate above it and then moves the stack pointer).
-template <class Stack, bool STATS>
-PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+template <class Stack, bool STATS, class Mem = GlobalMem>
+PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt, const Mem& mem = Mem())
 {
   // a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address arithmetic
   const uint32_t node_off = (uint32_t)tr.node * (uint32_t)sizeof(NodePair);
-  const char* node_at = reinterpret_cast<const char*>(sc.nodes) + node_off;
 #if defined(__HIP_DEVICE_COMPILE__) && PTK_TYPED_NODE_LOADS
+  const char* node_at = reinterpret_cast<const char*>(sc.nodes) + node_off;
   const ptk_v4i boxes = node_box_resource(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sizeof(NodePair));
   const ptk_v4f bx = ptk_buffer_load_format_xyzw(boxes, (int)node_off, 0, 0);  // lo0, hi0, lo1, hi1
   const ptk_v4f by = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 8, 0, 0);
   const ptk_v4f bz = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 16, 0, 0);
   const int32_t child0 = *reinterpret_cast<const int32_t*>(node_at + 24), child1 = *reinterpret_cast<const int32_t*>(node_at + 28);
 #else
-  const NodePair nd = *reinterpret_cast<const NodePair*>(node_at);  // loaded whole, by value: two 16-byte fetches
+  const NodePair nd = mem.node(sc, node_off);
   struct { float x, y, z, w; } bx, by, bz;
   bx.x = (float)(nd.x0 & 0xffffu); bx.y = (float)(nd.x0 >> 16); bx.z = (float)(nd.x1 & 0xffffu); bx.w = (float)(nd.x1 >> 16);
   by.x = (float)(nd.y0 & 0xffffu); by.y = (float)(nd.y0 >> 16); by.z = (float)(nd.y1 & 0xffffu); by.w = (float)(nd.y1 >> 16);
@@ -330,22 +366,17 @@ PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
   if (ok) { tr.hit.t = t; tr.hit.id = id; tr.hit.u = u; tr.hit.v = v; }
 }
 
-PTK_HD PrimRec load_prim(const SceneView& sc, uint32_t byte_offset)  // 32-bit byte offset, as for the nodes
-{
-  return *reinterpret_cast<const PrimRec*>(reinterpret_cast<const char*>(sc.prims) + byte_offset);
-}
-
 // Intersect the primitives of the leaf with code `node` (a negative child link).  Returns true when
 // the query is decided and needs no further traversal (see Traversal::t_stop).
-template <bool STATS>
-PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Counters& cnt)
+template <bool STATS, class Mem = GlobalMem>
+PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Counters& cnt, const Mem& mem = Mem())
 {
   const uint32_t leaf = ~(uint32_t)node;
   const uint32_t count = (leaf & 7u) + 1u;
   uint32_t off = (leaf >> 3) * (uint32_t)sizeof(PrimRec);
   // The next record is fetched while this one is tested.  Two records take turns (the loop is unrolled by two)
   // so that "next becomes current" is not ten register moves per primitive.
-  PrimRec p0 = load_prim(sc, off), p1 = p0;
+  PrimRec p0 = mem.prim(sc, off), p1 = p0;
   for (uint32_t i = 0;; i += 2) {
 #if defined(PTK_PHASE_STATS) && defined(__HIP_DEVICE_COMPILE__)
     {
@@ -354,12 +385,12 @@ PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Co
     }
 #endif
     const bool second = i + 1 < count;
-    if (second) p1 = load_prim(sc, off + (uint32_t)sizeof(PrimRec));
+    if (second) p1 = mem.prim(sc, off + (uint32_t)sizeof(PrimRec));
     trav_test_prim<STATS>(tr, p0, cnt);
     if (!second) break;
     const bool third = i + 2 < count;
     off += 2u * (uint32_t)sizeof(PrimRec);
-    if (third) p0 = load_prim(sc, off);
+    if (third) p0 = mem.prim(sc, off);
 #if defined(PTK_PHASE_STATS) && defined(__HIP_DEVICE_COMPILE__)
     {
       const unsigned long long active = __ballot(true);
@@ -373,10 +404,10 @@ PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Co
 }
 
 // Intersect the leaf the lane is at, then go on with the node on top of the stack.
-template <class Stack, bool STATS>
-PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt)
+template <class Stack, bool STATS, class Mem = GlobalMem>
+PTK_HD void trav_leaf(Traversal& tr, Stack& st, const SceneView& sc, Counters& cnt, const Mem& mem = Mem())
 {
-  const bool decided = trav_leaf_prims<STATS>(tr, tr.node, sc, cnt);
+  const bool decided = trav_leaf_prims<STATS, Mem>(tr, tr.node, sc, cnt, mem);
   const int32_t next_node = (int32_t)st.pop();
   tr.node = decided ? kTravDone : next_node;
 }
@@ -409,10 +440,11 @@ struct Surface {
 
 PTK_HD float atan2_ref(float y, float x) { return atan2f(y, x); }
 
-PTK_HD void make_surface(const SceneView& sc, v3 o, v3 d, const Hit& hit, Surface& s)
+template <class Mem = GlobalMem>
+PTK_HD void make_surface(const SceneView& sc, v3 o, v3 d, const Hit& hit, Surface& s, const Mem& mem = Mem())
 {
-  const ShadeRec sh = sc.shade[hit.id];
-  const MaterialRec& m = sc.materials[sh.material];
+  const auto& sh = mem.shade(sc, hit.id);
+  const auto& m = mem.material(sc, sh.material);
   s.id = hit.id;
   s.material = sh.material;
   s.point = o + d * hit.t;  // Ray::point_at, src/ray.h:8

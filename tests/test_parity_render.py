@@ -180,3 +180,23 @@ def test_image_sizes_that_do_not_fill_tiles(backend, width, height, request):
     b.render(32, 3, seed=17, band_rows=8, band_first=0, band_stride=2)
     banded, _ = b.render(32, 3, seed=17, band_rows=8, band_first=1, band_stride=2, reset=False)
     assert np.allclose(banded, got, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "cornell_pinhole"])
+def test_tiny_scene_form_renders_the_same_frame(name, gpu_ctx, monkeypatch):
+    """A scene of a few dozen primitives is rendered by the kernel form that keeps the whole scene in LDS
+    (ptk_layout.h: kTinyNodes ...).  Where the records are fetched from must not change a bit of the frame:
+    PTK_NO_TINY=1 at upload time selects the ordinary form for the same scene."""
+    sd = scene(name)
+    tiny = GpuBackend(gpu_ctx, sd)
+    assert tiny.info()["n_nodes"] <= 16 and tiny.info()["n_prims"] <= 24
+    img_tiny, cnt_tiny = tiny.render(64, 3, seed=5, collect_stats=False)
+    img_tiny_stats, cnt_tiny_stats = tiny.render(64, 3, seed=5, collect_stats=True)
+    monkeypatch.setenv("PTK_NO_TINY", "1")
+    plain = GpuBackend(gpu_ctx, sd)
+    img_plain, cnt_plain = plain.render(64, 3, seed=5, collect_stats=False)
+    _, cnt_plain_stats = plain.render(64, 3, seed=5, collect_stats=True)
+    assert np.array_equal(img_tiny, img_plain) and np.array_equal(img_tiny, img_tiny_stats)
+    assert cnt_tiny["queries"] == cnt_plain["queries"] and cnt_tiny["segments"] == cnt_plain["segments"]
+    assert cnt_tiny_stats["box_tests"] == cnt_plain_stats["box_tests"] and cnt_tiny_stats["prim_tests"] == cnt_plain_stats["prim_tests"]

@@ -43,7 +43,7 @@ if "SQ_INSTS_VALU_FMA_F32" in per:
     rest = per["SQ_INSTS_VALU"] - fast - trans
     # measured issue cost per wave64 instruction (tools/ubench/valu_rate.hip): fma/mul/add 2 cycles, transcendentals 8,
     # everything else 4 at most (moves, and/or/xor and integer adds are 2: they cannot be told apart here, so this is an upper bound)
-    out[key].update({"valu_fast_share": fast / per["SQ_INSTS_VALU"], "valu_pipe_occupancy_upper": (2.0 * fast + 4.0 * rest + 8.0 * trans) / (1024.0 * kernel_cycles),
+    out[key].update({"valu_fast_share": fast / per["SQ_INSTS_VALU"], "valu_pipe_occupancy_upper": min(1.0, (2.0 * fast + 4.0 * rest + 8.0 * trans) / (1024.0 * kernel_cycles)),
                      "valu_pipe_occupancy_lower": 2.0 * per["SQ_INSTS_VALU"] / (1024.0 * kernel_cycles)})
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[key]))

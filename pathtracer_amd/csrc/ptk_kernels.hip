@@ -88,22 +88,66 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
 #endif
-template <int DEPTH>
+// OVER > 0: the stack may grow OVER entries beyond its DEPTH entries of LDS.  Those entries live in the lane's
+// private memory (`over`, a few words of scratch).  A traversal stack holds one entry per level at which BOTH
+// children were hit and the far one still waits, so even in a 25-level tree more than twenty pending entries is a
+// rarity; every operation first asks, for the whole wave at once (one compare and a scalar branch), whether any
+// lane is that far up, and only then takes the path that looks at each entry's level.  This is what lets deep
+// trees run with the LDS footprint - and so the resident waves - of shallow ones.
+template <int DEPTH, int OVER = 0>
 struct LdsStack {
   static constexpr int kDepth = DEPTH;
   static constexpr int kStep = PTK_STACK_LANE_MAJOR ? 1 : kBlock;  // words between a lane's consecutive entries
-  uint32_t* top;   // this lane's top entry
+  static_assert(OVER == 0 || PTK_STACK_LANE_MAJOR, "the overflow entries assume lane-major stacks");
+  uint32_t* top;   // this lane's top entry (beyond base + DEPTH - 1: an address that is never touched, only counted with)
   uint32_t* base;  // this lane's entry 0
-  __device__ __forceinline__ void attach(uint32_t* array, int lane) { base = top = array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane); }
+  uint32_t* over;  // entries DEPTH, DEPTH + 1, ...: an array of OVER words in the lane's private memory (its own object, so
+                   // that top and base stay in registers)
+  static constexpr int kOver = OVER > 0 ? OVER : 1;
+  __device__ __forceinline__ void attach(uint32_t* array, int lane, uint32_t* over_entries = nullptr)
+  {
+    base = top = array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane);
+    over = over_entries;
+  }
   __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
-  __device__ __forceinline__ void push(uint32_t v) { top += kStep; *top = v; }
-  __device__ __forceinline__ uint32_t pop() { uint32_t v = *top; top -= kStep; return v; }
-  // Branch-free: the entry above the top is scratch, so v is always written there and only counts
-  // if the top moves up.  The builder keeps trees shallower than the stack (ptk_upload_scene checks).
+  // entry at address p, wherever it lives
+  __device__ __forceinline__ uint32_t read_at(const uint32_t* p) const
+  {
+    const int level = (int)(p - base);
+    return level < DEPTH ? *p : over[min(level - DEPTH, OVER - 1)];
+  }
+  __device__ __forceinline__ void write_at(uint32_t* p, uint32_t v)
+  {
+    const int level = (int)(p - base);
+    if (level < DEPTH) *p = v;
+    else over[min(level - DEPTH, OVER - 1)] = v;
+  }
+  // true when some lane's entry at `p` or above may lie outside LDS
+  __device__ __forceinline__ bool any_beyond(const uint32_t* p) const { return OVER > 0 && __builtin_expect(__ballot(p >= base + DEPTH) != 0ull, 0); }
+  __device__ __forceinline__ void push(uint32_t v)
+  {
+    top += kStep;
+    if (any_beyond(top)) write_at(top, v);
+    else *top = v;
+  }
+  __device__ __forceinline__ uint32_t pop()
+  {
+    const uint32_t v = any_beyond(top) ? read_at(top) : *top;
+    top -= kStep;
+    return v;
+  }
+  // Branch-free on the usual path: the entry above the top is scratch, so v is always written there and only
+  // counts if the top moves up.  The builder keeps trees shallower than DEPTH + OVER - 2 (ptk_upload_scene checks).
   __device__ __forceinline__ uint32_t step(bool do_push, uint32_t v, bool do_pop)
   {
-    uint32_t t = *top;
-    top[kStep] = v;
+    uint32_t t;
+    if (any_beyond(top + kStep)) {
+      t = read_at(top);
+      write_at(top + kStep, v);
+    } else {
+      t = *top;
+      top[kStep] = v;
+    }
     // at most one of the two is set; a byte step of +-4 (lane-major) is an inline constant of the select
     const int step_bytes = do_push ? kStep * 4 : (do_pop ? -kStep * 4 : 0);
     top = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top) + step_bytes);
@@ -188,14 +232,15 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
 // The kernel's forms (see ptk_layout.h: stack size, LDS, waves per SIMD): kFormShallow for trees of at most
 // kShallowTreeDepth levels, kFormDeep for deeper ones, kFormTiny for scenes whose whole tree and primitive records
 // fit a few KB of LDS (traversed from there).
-constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2;
+constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2, kFormSpill = 3;
 template <bool STATS, int FORM>
 __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
     SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra, f4* __restrict__ accum, f4* __restrict__ partial,
     unsigned long long* counters)
 {
   constexpr bool DEEP = FORM == kFormDeep, TINY = FORM == kFormTiny;
-  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : (TINY ? kStackDepthTiny : kStackDepthShallow)>;
+  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : (TINY ? kStackDepthTiny : kStackDepthShallow),
+                                 FORM == kFormSpill ? kStackDepth - kStackDepthShallow : 0>;
   using Mem = typename std::conditional<TINY, LdsMem, GlobalMem>::type;
   constexpr int kSceneChunks = (kTinyNodes * sizeof(NodePair) + kTinyPrims * (sizeof(PrimRec) + sizeof(ShadeRec)) +
                                 kTinyMaterials * sizeof(MaterialRec) + kTinyLights * sizeof(LightRec)) / sizeof(f4);
@@ -223,7 +268,8 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
-  st.attach(lds_stack, (int)threadIdx.x);
+  uint32_t stack_over[LdsStack::kOver];
+  st.attach(lds_stack, (int)threadIdx.x, stack_over);
 
   // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
   // tile, then the next tile of the same tile row; tile rows are dealt to the XCDs round-robin
@@ -417,7 +463,8 @@ template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
                                                            ptk_hit* __restrict__ hits, unsigned long long* counters)
 {
-  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : kStackDepthShallow>;
+  // (a test build with a very short shallow stack keeps the full one here: a lane's stack region also stages its hit record)
+  using LdsStack = ptk::LdsStack<(DEEP || kStackDepthShallow < 16) ? kStackDepth : kStackDepthShallow>;
   __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ uint32_t lds_finished[kBlock];  // the lanes whose records wait to be written out, in rank order
 #ifdef PTK_INTERSECT_LDS_PAD
@@ -447,7 +494,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
   // stack region, and the whole wave then copies the finished records out with consecutive lanes writing
   // consecutive words, so that a store instruction covers whole records.
   constexpr uint32_t kRecordWords = sizeof(ptk_hit) / 4;
-  static_assert(sizeof(ptk_hit) % 4 == 0 && kRecordWords + 2 <= (uint32_t)kStackDepthShallow && PTK_STACK_LANE_MAJOR,
+  static_assert(sizeof(ptk_hit) % 4 == 0 && kRecordWords + 2 <= (uint32_t)LdsStack::kDepth && PTK_STACK_LANE_MAJOR,
                 "a hit record and its ray index must fit a lane's stack region above the sentinel");
   for (;;) {
     const bool done = trav_done(tr);
@@ -572,6 +619,7 @@ struct ptk_ctx {
   bool have_scene = false;
   bool deep_tree = true;         // the tree has more than kShallowTreeDepth levels: the kernels' deep form runs
   bool tiny_scene = false;       // the tree and the primitive records fit the render kernel's LDS copy: its tiny form runs
+  bool spill_stack = false;      // deep tree rendered with the shallow form's LDS stack plus overflow entries in private memory
   bool have_scene_host = false;  // `host` still holds everything another context would need (ctx_upload_like)
   int32_t builder_asked = 0;
   HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
@@ -756,6 +804,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
     return fail(ctx, PTK_ERR_LIMIT, "ptk_upload_scene: the tree is deeper than the traversal stack");
   }
   ctx->deep_tree = h.max_depth > kShallowTreeDepth || getenv("PTK_FORCE_DEEP") != nullptr;
+  ctx->spill_stack = ctx->deep_tree && getenv("PTK_DEEP_LDS") == nullptr;  // PTK_DEEP_LDS=1: the 27-entry LDS stack at 5 waves per SIMD
   ctx->tiny_scene = !ctx->deep_tree && h.max_depth <= kTinyTreeDepth && ctx->n_nodes <= kTinyNodes && h.n_prims <= kTinyPrims && h.n_prims > 0 &&
                     (int)h.materials.size() <= kTinyMaterials && (int)h.lights.size() <= kTinyLights &&
                     getenv("PTK_NO_TINY") == nullptr;
@@ -985,7 +1034,7 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int tiles_y = (launch_rows + kTile - 1) / kTile;
   ra.rows = tiles_y * kTile;
   ra.n_tiles = ra.tiles_x * tiles_y;
-  ra.chunks = pick_chunks(ra.n_tiles, p->samples, ctx->deep_tree ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
+  ra.chunks = pick_chunks(ra.n_tiles, p->samples, ctx->deep_tree && !ctx->spill_stack ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
   PTK_HIP(hipSetDevice(ctx->device));
   size_t band_pixels = (size_t)ra.rows * (size_t)ctx->cam.width;
   f4* partial = ctx->d_partial;
@@ -1017,7 +1066,8 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
-  auto kernel = ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
+  auto kernel = ctx->spill_stack  ? (p->collect_stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>)
+                : ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
                 : ctx->tiny_scene ? (p->collect_stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>)
                                   : (p->collect_stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>);
   hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters);

@@ -24,7 +24,10 @@ constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
 #define PTK_STACK_DEPTH 27
 #endif
 constexpr int kStackDepth = PTK_STACK_DEPTH;   // deep form: the largest stack
-constexpr int kStackDepthShallow = 22;
+#ifndef PTK_STACK_DEPTH_SHALLOW
+#define PTK_STACK_DEPTH_SHALLOW 22
+#endif
+constexpr int kStackDepthShallow = PTK_STACK_DEPTH_SHALLOW;  // (smaller in test builds, to exercise the overflow entries)
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
 // Tiny scenes (the Cornell box: 5 nodes, 12 triangles, 6 materials, 2 lights): the render kernel has a third form

@@ -40,7 +40,7 @@ constexpr int kTinyNodes = 16, kTinyPrims = 24, kTinyMaterials = 8, kTinyLights 
 // Inner node with the boxes of BOTH children, 32 bytes.  The render kernel is bound by the number of bytes its
 // lanes pull through the L1 (every lane is at its own node), which is why the boxes are not stored as floats:
 // box planes are 16-bit positions on a grid over the scene's bounds (BoxGrid), rounded outwards, low plane in
-// the low half of a word and high plane in the high half.  The words of one axis sit next to each other, child
+// the low half of a word and the box's extent (high plane - low plane) in the high half.  The words of one axis sit next to each other, child
 // 0 first, so that one typed 8-byte load (four 16-bit integers -> four floats, converted by the memory pipeline)
 // brings an axis of both boxes: three such loads and one 8-byte load of the links per visit.
 // child >= 0: index of an inner node.  child < 0: leaf, ~child = (first_prim << 3) | (count - 1).
@@ -84,7 +84,8 @@ PTK_HD uint32_t grid_ceil(float v, float origin, float scale)
 }
 PTK_HD uint32_t grid_word(float lo, float hi, float origin, float scale)
 {
-  return grid_floor(lo, origin, scale) | (grid_ceil(hi, origin, scale) << 16);
+  const uint32_t q_lo = grid_floor(lo, origin, scale), q_hi = grid_ceil(hi, origin, scale);
+  return q_lo | ((q_hi - q_lo) << 16);  // low plane | extent: the slab test wants the extent (hit_box), and this way it is one conversion
 }
 PTK_HD void set_child_box(NodePair& n, int which, const float lo[3], const float hi[3], const BoxGrid& g)
 {

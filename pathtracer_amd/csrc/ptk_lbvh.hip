@@ -123,22 +123,23 @@ __global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t
   nodes[i].child1 = c1;
 }
 
-// A box as the nodes store it: per axis, low grid plane | high grid plane << 16.
+// A box as the nodes store it: per axis, low grid plane | (high plane - low plane) << 16.
 struct QBox {
   uint32_t x, y, z;
 };
 
 __device__ inline uint32_t q_union(uint32_t a, uint32_t b)
 {
-  uint32_t lo = min(a & 0xffffu, b & 0xffffu), hi = max(a >> 16, b >> 16);
-  return lo | (hi << 16);
+  const uint32_t lo_a = a & 0xffffu, lo_b = b & 0xffffu;
+  const uint32_t lo = min(lo_a, lo_b), hi = max(lo_a + (a >> 16), lo_b + (b >> 16));
+  return lo | ((hi - lo) << 16);
 }
 
 __device__ inline float q_half_area(const QBox& b, const BoxGrid& g)
 {
-  float dx = (float)((b.x >> 16) - (b.x & 0xffffu)) * g.scale[0];
-  float dy = (float)((b.y >> 16) - (b.y & 0xffffu)) * g.scale[1];
-  float dz = (float)((b.z >> 16) - (b.z & 0xffffu)) * g.scale[2];
+  float dx = (float)(b.x >> 16) * g.scale[0];
+  float dy = (float)(b.y >> 16) * g.scale[1];
+  float dz = (float)(b.z >> 16) * g.scale[2];
   return dx * dy + dy * dz + dz * dx;
 }
 

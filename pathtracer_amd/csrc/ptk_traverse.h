@@ -96,13 +96,13 @@ PTK_HD float min_raw(float a, float b)
 #endif
 }
 
-// Slab test of one child box against [0, tbest]; returns the entry distance in tn.  (lo, hi): the box's grid
-// planes per axis, as floats.  The ray carries inv = grid scale / d and oi = (o - grid origin) / d per axis, so
+// Slab test of one child box against [0, tbest]; returns the entry distance in tn.  (lo, e): the box's low grid
+// plane and its extent hi - lo per axis, as floats (what the node stores).  The ray carries inv = grid scale / d and oi = (o - grid origin) / d per axis, so
 // the distance to grid plane q is fma(q, inv, -oi).  Which of an axis' two planes is the near one depends on
 // the sign of d only, so the ray also carries inv split by sign (neg = min(inv, 0), pos = max(inv, 0)) and the
 // two distances are
-//     near = t(lo) + (hi - lo) * neg,   far = t(lo) + (hi - lo) * pos
-// - a subtraction and three fused multiply-adds per axis, all of which issue at the full vector rate on this
+//     near = t(lo) + e * neg,   far = t(lo) + e * pos
+// - three fused multiply-adds per axis, all of which issue at the full vector rate on this
 // hardware (v_min_f32 / v_max_f32 take twice as long as v_fma_f32: see tools/ubench/valu_rate.hip).
 // The caller keeps 1/d finite (axis-parallel rays get +-1e20), so a slab the origin lies in gives -huge..+huge
 // and a slab it lies outside gives two huge values of one sign.  The rounding of these products is covered by
@@ -118,11 +118,11 @@ PTK_HD RaySlabs ray_slabs(v3 inv, v3 oi)
   r.pos = V3(inv.x - r.neg.x, inv.y - r.neg.y, inv.z - r.neg.z);
   return r;
 }
-PTK_HD bool hit_box(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi, const RaySlabs& r, float tbest, float& tn)
+PTK_HD bool hit_box(float xlo, float ex, float ylo, float ey, float zlo, float ez, const RaySlabs& r, float tbest, float& tn)
 {
-  const float tx = fmaf(xlo, r.inv.x, -r.oi.x), ex = xhi - xlo;
-  const float ty = fmaf(ylo, r.inv.y, -r.oi.y), ey = yhi - ylo;
-  const float tz = fmaf(zlo, r.inv.z, -r.oi.z), ez = zhi - zlo;
+  const float tx = fmaf(xlo, r.inv.x, -r.oi.x);
+  const float ty = fmaf(ylo, r.inv.y, -r.oi.y);
+  const float tz = fmaf(zlo, r.inv.z, -r.oi.z);
   const float nx = fmaf(ex, r.neg.x, tx), fx = fmaf(ex, r.pos.x, tx);
   const float ny = fmaf(ey, r.neg.y, ty), fy = fmaf(ey, r.pos.y, ty);
   const float nz = fmaf(ez, r.neg.z, tz), fz = fmaf(ez, r.pos.z, tz);
@@ -291,7 +291,7 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
 #if defined(__HIP_DEVICE_COMPILE__) && PTK_TYPED_NODE_LOADS
   const char* node_at = reinterpret_cast<const char*>(sc.nodes) + node_off;
   const ptk_v4i boxes = node_box_resource(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sizeof(NodePair));
-  const ptk_v4f bx = ptk_buffer_load_format_xyzw(boxes, (int)node_off, 0, 0);  // lo0, hi0, lo1, hi1
+  const ptk_v4f bx = ptk_buffer_load_format_xyzw(boxes, (int)node_off, 0, 0);  // low plane and extent of child 0, of child 1
   const ptk_v4f by = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 8, 0, 0);
   const ptk_v4f bz = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 16, 0, 0);
   const int32_t child0 = *reinterpret_cast<const int32_t*>(node_at + 24), child1 = *reinterpret_cast<const int32_t*>(node_at + 28);

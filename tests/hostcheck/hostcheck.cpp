@@ -75,7 +75,7 @@ void hc_tree_check(void* h, int64_t* out)
     const uint32_t w[3] = {wx, wy, wz};
     for (int a = 0; a < 3; a++) {
       t.lo[a] = (double)g.origin[a] + (double)(w[a] & 0xffffu) * (double)g.scale[a];
-      t.hi[a] = (double)g.origin[a] + (double)(w[a] >> 16) * (double)g.scale[a];
+      t.hi[a] = (double)g.origin[a] + (double)((w[a] & 0xffffu) + (w[a] >> 16)) * (double)g.scale[a];  // low plane + extent
     }
   };
   const NodePair& root = hs.nodes[0];

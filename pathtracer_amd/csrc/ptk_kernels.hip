@@ -92,38 +92,61 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 // private memory (`over`, a few words of scratch).  A traversal stack holds one entry per level at which BOTH
 // children were hit and the far one still waits, so even in a 25-level tree more than twenty pending entries is a
 // rarity; every operation first asks, for the whole wave at once (one compare and a scalar branch), whether any
-// lane is that far up, and only then takes the path that looks at each entry's level.  This is what lets deep
-// trees run with the LDS footprint - and so the resident waves - of shallow ones.
+// lane is that far up, and only then takes the path that looks at each entry's level.  Even that question is asked
+// rarely: `room` counts how many more pushes every lane of the wave can certainly take (refresh(), one ballot, grants
+// kRoom of them when no lane is within kRoom entries of the end of its LDS part; the caller takes one off per
+// wave-wide step), and while it is positive no operation checks anything.  This is what lets deep trees run with the
+// LDS footprint - and so the resident waves - of shallow ones.
 template <int DEPTH, int OVER = 0>
 struct LdsStack {
   static constexpr int kDepth = DEPTH;
   static constexpr int kStep = PTK_STACK_LANE_MAJOR ? 1 : kBlock;  // words between a lane's consecutive entries
   static_assert(OVER == 0 || PTK_STACK_LANE_MAJOR, "the overflow entries assume lane-major stacks");
-  uint32_t* top;   // this lane's top entry (beyond base + DEPTH - 1: an address that is never touched, only counted with)
-  uint32_t* base;  // this lane's entry 0
-  uint32_t* over;  // entries DEPTH, DEPTH + 1, ...: an array of OVER words in the lane's private memory (its own object, so
-                   // that top and base stay in registers)
+  // Pointers in the LDS address space (32 bits, ds_read / ds_write), stated explicitly: once the overflow path
+  // selects between an LDS and a private address the compiler no longer works that out by itself and falls back to
+  // 64-bit generic pointers and flat loads for every stack access.
+  using Word = PTK_LDS_SPACE uint32_t;
+  Word* top;   // this lane's top entry (beyond base + DEPTH - 1: an address that is never touched, only counted with)
+  Word* base;  // this lane's entry 0
+  volatile uint32_t* over;  // entries DEPTH, DEPTH + 1, ...: an array of OVER words in the lane's private memory (its own
+                            // object, so that top and base stay in registers; volatile, so that it stays memory and is
+                            // not turned into OVER more live registers)
   static constexpr int kOver = OVER > 0 ? OVER : 1;
-  __device__ __forceinline__ void attach(uint32_t* array, int lane, uint32_t* over_entries = nullptr)
+  static constexpr int kRoom = 8;
+  int room;  // wave-uniform: every lane's top is at or below base + DEPTH - 2 - room (meaningless when it is <= 0)
+  __device__ __forceinline__ void attach(uint32_t* array, int lane, volatile uint32_t* over_entries = nullptr)
   {
-    base = top = array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane);
+    base = top = (Word*)array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane);
     over = over_entries;
+    room = 0;
   }
+  // To be called with all lanes of the wave active, before a wave-wide step; the caller then takes one off `room`.
+  __device__ __forceinline__ void refresh()
+  {
+    if (OVER > 0 && room <= 0) room = __ballot(top > base + (DEPTH - 2 - kRoom)) == 0ull ? kRoom : 0;
+  }
+  __device__ __forceinline__ void stepped() { if (OVER > 0) room -= 1; }
   __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
   // entry at address p, wherever it lives
-  __device__ __forceinline__ uint32_t read_at(const uint32_t* p) const
+  __device__ __forceinline__ uint32_t read_at(const Word* p) const
   {
     const int level = (int)(p - base);
-    return level < DEPTH ? *p : over[min(level - DEPTH, OVER - 1)];
+    uint32_t v;
+    if (level < DEPTH) v = *p;
+    else v = over[min(level - DEPTH, OVER - 1)];
+    return v;
   }
-  __device__ __forceinline__ void write_at(uint32_t* p, uint32_t v)
+  __device__ __forceinline__ void write_at(Word* p, uint32_t v)
   {
     const int level = (int)(p - base);
     if (level < DEPTH) *p = v;
     else over[min(level - DEPTH, OVER - 1)] = v;
   }
   // true when some lane's entry at `p` or above may lie outside LDS
-  __device__ __forceinline__ bool any_beyond(const uint32_t* p) const { return OVER > 0 && __builtin_expect(__ballot(p >= base + DEPTH) != 0ull, 0); }
+  __device__ __forceinline__ bool any_beyond(const Word* p) const
+  {
+    return OVER > 0 && room <= 0 && __builtin_expect(__ballot(p >= base + DEPTH) != 0ull, 0);
+  }
   __device__ __forceinline__ void push(uint32_t v)
   {
     top += kStep;
@@ -149,8 +172,8 @@ struct LdsStack {
       top[kStep] = v;
     }
     // at most one of the two is set; a byte step of +-4 (lane-major) is an inline constant of the select
-    const int step_bytes = do_push ? kStep * 4 : (do_pop ? -kStep * 4 : 0);
-    top = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(top) + step_bytes);
+    const int step_words = do_push ? kStep : (do_pop ? -kStep : 0);
+    top += step_words;
     return t;
   }
 };
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
   LdsStack st;
-  uint32_t stack_over[LdsStack::kOver];
+  volatile uint32_t stack_over[LdsStack::kOver];
   st.attach(lds_stack, (int)threadIdx.x, stack_over);
 
   // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     // (Descending past a leaf uses a closest-hit distance that is not up to date, which costs a few extra
     // node visits and never a wrong answer.  Holding one leaf: +13 % frame rate; holding two: -6 %.)
     for (;;) {
+      st.refresh();
       if (trav_at_leaf(ps.tr) && held == kTravDone) { held = ps.tr.node; ps.tr.node = (int32_t)st.pop(); }
       const bool want = trav_at_inner(ps.tr);
       const int n_want = __popcll(__ballot(want));
@@ -353,6 +377,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<LdsStack, STATS, Mem>(ps.tr, st, sc, cnt, mem);
+      st.stepped();
     }
     PTK_PHASE_CLOCK(0)
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
           out.uv[0] = s.uv[0]; out.uv[1] = s.uv[1];
           out.material = (int32_t)s.material; out.inside = s.inside ? 1 : 0;
         }
-        uint32_t* rec = st.base + 1;
+        auto* rec = st.base + 1;
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&out);
 #pragma unroll
         for (uint32_t k = 0; k < kRecordWords; k++) rec[k] = w[k];

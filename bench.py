@@ -238,6 +238,11 @@ def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a box with one GPU: every rank on GPU 0, collectives through gloo (RCCL refuses two
+    # ranks on one device).  Not a measurement.
+    rehearsal = os.environ.get("BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if not torch.cuda.is_available():
@@ -246,7 +251,10 @@ def main(args):
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})", file=sys.stderr, flush=True)
 
     names = ["bunny", "cornell", "bmw"] if args.workload == "all" else [args.workload]

@@ -1,10 +1,17 @@
 // Plain-C handles on the host library for scripted checks (ctypes): image decode / encode and OBJ loading
 // through exactly the code paths Scene and Image use.  Nothing here touches the GPU.
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include <fstream>
+#include <iterator>
+#include <string>
+
 #include "image.h"
+#include "json.h"
 #include "scene.h"
 
 extern "C" {
@@ -61,6 +68,44 @@ int pt_host_load_obj(const char* path, int cap, double* pos, double* nrm, double
   }
   if (n_lights) *n_lights = scene.light_count();
   return n;
+}
+
+// Parses a configuration file with the driver's JSON reader and flattens it to "path=value" lines (objects by
+// key, arrays by index; numbers with 17 digits).  Returns the number of bytes needed (including the final 0), or -1
+// when the file cannot be read or parsed.
+int pt_host_json_flatten(const char* path, char* out, int cap)
+{
+  std::ifstream file(path);
+  if (!file.is_open()) return -1;
+  const std::string text((std::istreambuf_iterator<char>(file)), std::istreambuf_iterator<char>());
+  std::string flat;
+  try {
+    const pt::Json doc = pt::JsonParser(text).parse();
+    struct Walk {
+      std::string& flat;
+      void operator()(const pt::Json& v, const std::string& at)
+      {
+        char number[64];
+        switch (v.kind) {
+          case pt::Json::Object: for (const auto& kv : v.obj) (*this)(kv.second, at.empty() ? kv.first : at + "." + kv.first); break;
+          case pt::Json::Array: for (size_t i = 0; i < v.arr.size(); i++) (*this)(v.arr[i], at + "[" + std::to_string(i) + "]"); break;
+          case pt::Json::Number: std::snprintf(number, sizeof number, "%.17g", v.num); flat += at + "=" + number + "\n"; break;
+          case pt::Json::String: flat += at + "=" + v.str + "\n"; break;
+          case pt::Json::Bool: flat += at + "=" + (v.b ? "true" : "false") + "\n"; break;
+          default: flat += at + "=null\n"; break;
+        }
+      }
+    } walk{flat};
+    walk(doc, "");
+  } catch (const std::exception&) {
+    return -1;
+  }
+  if (out && cap > 0) {
+    const size_t n = std::min(flat.size(), (size_t)cap - 1);
+    std::memcpy(out, flat.data(), n);
+    out[n] = 0;
+  }
+  return (int)flat.size() + 1;
 }
 
 }  // extern "C"

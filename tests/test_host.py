@@ -380,3 +380,70 @@ def test_image_decoders_reject_damaged_files_under_address_sanitizer(tmp_path):
         assert r.returncode == 0, (r.stdout[-300:], r.stderr[-1500:])
     first = subprocess.run([str(exe), files[0], str(tmp_path / "sel64.jpg"), str(tmp_path / "depth3.png")], capture_output=True, text=True)
     assert "decoded 1 rejected 2" in first.stdout, first.stdout
+
+
+REFERENCE_ASSETS = "/root/reference/assets"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_ASSETS), reason="the reference checkout is not on this machine")
+def test_the_references_own_asset_files(host):
+    """The files the reference ships for its one scene, read as data by this build's readers: the configuration by
+    the driver's JSON reader (against Python's), the Cornell box OBJ + MTL by the OBJ reader (it must give the
+    procedural scene the benchmarks use, bit for bit), the two textures by the PNG and JPEG decoders (against
+    Pillow's).  Runs where the reference checkout exists; the GPU box has none and needs none."""
+    import json
+    # configuration
+    cfg = os.path.join(REFERENCE_ASSETS, "cornell_box", "cornell_box.json")
+    host.pt_host_json_flatten.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    need = host.pt_host_json_flatten(cfg.encode(), None, 0)
+    assert need > 0
+    buf = C.create_string_buffer(need)
+    assert host.pt_host_json_flatten(cfg.encode(), buf, need) == need
+    got = dict(line.split("=", 1) for line in buf.value.decode().splitlines())
+
+    def flatten(v, at, out):
+        if isinstance(v, dict):
+            for k, x in v.items():
+                flatten(x, f"{at}.{k}" if at else k, out)
+        elif isinstance(v, list):
+            for i, x in enumerate(v):
+                flatten(x, f"{at}[{i}]", out)
+        elif isinstance(v, bool):
+            out[at] = "true" if v else "false"
+        elif isinstance(v, (int, float)):
+            out[at] = "%.17g" % float(v)
+        else:
+            out[at] = str(v)
+        return out
+    want = flatten(json.load(open(cfg)), "", {})
+    assert got == want and got["camera_fov"] == "14.5" and got["spheres[2].hidden"] == "true"
+
+    # geometry and materials
+    sd = scenes.cornell_box(32, 32)
+    n = 64
+    pos, nrm, uv = np.zeros((n, 9)), np.zeros((n, 9)), np.zeros((n, 6))
+    mtype, tex = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    alb, emi = np.zeros((n, 3)), np.zeros((n, 3))
+    nl = C.c_int()
+    k = host.pt_host_load_obj(os.path.join(REFERENCE_ASSETS, "cornell_box", "cornell_box.obj").encode(), n, pos.ctypes.data,
+                              nrm.ctypes.data, uv.ctypes.data, mtype.ctypes.data, alb.ctypes.data, emi.ctypes.data,
+                              tex.ctypes.data, C.byref(nl))
+    assert k == 12 and nl.value == 2
+    assert np.array_equal(pos[:12].reshape(12, 3, 3), sd.tri_pos)
+    assert np.array_equal(nrm[:12].reshape(12, 3, 3), sd.tri_nrm)
+    assert np.array_equal(uv[:12].reshape(12, 3, 2), sd.tri_uv)
+    for i in range(12):
+        m = sd.materials[sd.tri_mat[i]]
+        assert mtype[i] == m.type and np.allclose(alb[i], m.albedo) and np.allclose(emi[i], m.emission)
+        assert tex[i] == (1 if m.texture >= 0 else 0)
+
+    # textures
+    png = os.path.join(REFERENCE_ASSETS, "textures", "uv-test.png")
+    got_png = _load(host, png)
+    assert got_png is not None and np.array_equal(got_png, np.flipud(np.asarray(Image.open(png).convert("RGB"))))
+    jpg = os.path.join(REFERENCE_ASSETS, "textures", "prater.jpg")
+    got_jpg = _load(host, jpg)
+    expect = np.flipud(np.asarray(Image.open(jpg).convert("RGB"))).astype(int)
+    assert got_jpg is not None and got_jpg.shape == expect.shape == (1792, 3584, 3)
+    d = np.abs(got_jpg.astype(int) - expect)
+    assert d.mean() < 1.5 and np.percentile(d, 99.9) <= 12  # IDCT / chroma upsampling latitude, as for the generated files

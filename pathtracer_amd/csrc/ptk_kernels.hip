@@ -69,7 +69,9 @@ constexpr int kMaxChunks = 32;
 // device address).  Every call on a GPU shares that GPU's copy.
 constexpr size_t kStaticScratchBytes = (size_t)128 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
-constexpr int kCounterSlots = 24;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters and 16-20 phase clocks of a PTK_PHASE_STATS build
+constexpr int kCounterSlots = 24;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters and 16-20 phase clocks of a PTK_PHASE_STATS build, 22 the ray-batch kernel's work counter
+constexpr int kIntersectQueueSlot = 22;
+constexpr int kIntersectRunMax = 1024;  // most rays a wave draws from the work counter at a time
 
 // A build with -DPTK_PHASE_STATS makes instrumented launches also count, per wave, how often each
 // phase of the render loop ran and how many lanes it ran for (printed by ptk_get_stats when the
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(f4* __restrict__ acc
 #endif
 template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(SceneView sc, const float* __restrict__ rays, int n,
-                                                           ptk_hit* __restrict__ hits, unsigned long long* counters)
+                                                           ptk_hit* __restrict__ hits, unsigned long long* counters, int run)
 {
   // (a test build with a very short shallow stack keeps the full one here: a lane's stack region also stages its hit record)
   using LdsStack = ptk::LdsStack<(DEEP || kStackDepthShallow < 16) ? kStackDepth : kStackDepthShallow>;
@@ -500,13 +502,19 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
   st.attach(lds_stack, (int)threadIdx.x);
   const uint32_t lane = threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
-  // A wave owns a contiguous run of the batch (the grid is capped by launch_intersect: a quarter of a million
-  // one-shot workgroups, each ending in counter atomics, cost ten times the traversal) and works through it
-  // like the render kernel works through a tile: lanes take the next rays as their queries finish, and the
-  // wave alternates descend / leaf / hand-over phases.
-  const long long per = (((long long)n + gridDim.x - 1) / gridDim.x + kBlock - 1) / kBlock * kBlock;
-  long long next = (long long)blockIdx.x * per;  // wave-uniform
-  const long long end = next + per < (long long)n ? next + per : (long long)n;
+  // The launch holds one round of resident waves (launch_intersect): every further round of workgroups was
+  // measured to cost as much as the first.  A wave starts on the run of `run` consecutive rays of its
+  // own number, then draws further runs from a counter in device memory until the batch is used up, and works
+  // through a run like the render kernel works through a tile: lanes take the next rays as their queries
+  // finish, and the wave alternates descend / leaf / hand-over phases.  Drawing (rather than owning a fixed
+  // share) keeps all waves reading rays and writing records near one moving front, which the address
+  // translation likes (+35 % on 64 M rays), and evens out costly and cheap regions.  Draws from one address
+  // complete at about 70 M/s, so runs are as long as the batch allows (launch_intersect); shorter runs towards the end of a batch (tried: a quarter
+  // and a sixteenth over the last two draws per wave) cost more in draws than they save in waiting.
+  unsigned long long* const queue = counters + kIntersectQueueSlot;
+  long long next = 0, end = 0;  // wave-uniform: the run in hand
+  bool more = true;             // wave-uniform: the runs drawn so far do not reach the end of the batch
+  bool first = true;
   Traversal tr;
   tr.node = kTravDone;
   tr.o = tr.d = V3(0.f, 0.f, 0.f);
@@ -565,10 +573,23 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
         }
         __syncthreads();  // the stack regions are reused by the queries that start below
       }
+      if (next >= end && more) {  // wave-uniform
+        // a wave's first run is the one of its own number: the counter hands out the runs after those
+        unsigned long long got = 0ull;
+        if (!first && lane == 0) got = atomicAdd(queue, 1ull);
+        const long long i = first ? (long long)blockIdx.x
+                                  : (long long)gridDim.x + (long long)__builtin_amdgcn_readfirstlane((uint32_t)got);  // fewer than 2^31 / 64 draws
+        first = false;
+        next = i * run;
+        end = next + run < (long long)n ? next + run : (long long)n;
+        more = next + run < (long long)n;
+      }
+      // a lane that finds the run used up keeps asking (the next pass draws a new run) until the batch is used up
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
       const long long take = next + rank;
       next += __popcll(need_mask);
       if (need) {
+        mine = -1;
         if (take < end) {
           // origin and direction as three 8-byte loads (a ray is 24 bytes, 8-byte aligned)
           const float2* r = reinterpret_cast<const float2*>(rays) + 3 * (size_t)take;
@@ -578,9 +599,8 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
           const v3 o = V3(a.x, a.y, b.x), d = V3(b.y, c.x, c.y);
           shift = scene_entry_shift(sc, o, d);
           trav_begin(tr, st, sc, o + d * shift, d, kTMax, kNoPrim);
-        } else {
+        } else if (!more) {
           alive = false;
-          mine = -1;
         }
       }
     }
@@ -598,7 +618,9 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
     }
     if (trav_at_leaf(tr)) trav_leaf<LdsStack, STATS>(tr, st, sc, cnt);
   }
-  flush_counters(cnt, counters);
+  // The waves of a batch end together, and counter updates to one address complete one after another at about
+  // 14 ns each: five per wave were 0.4 ms of a 1.5 ms batch.  Without statistics the host counts the rays.
+  if (STATS) flush_counters(cnt, counters);
 }
 
 // What Renderer::save_image does to every pixel before the file is written (src/renderer.cpp:174-192):
@@ -676,10 +698,12 @@ struct ptk_ctx {
   size_t stage_capacity = 0;  // in rays
   // counters and timing
   unsigned long long* d_counters = nullptr;
+  int intersect_resident[2] = {0, 0};  // waves of the ray-batch kernel that fit the GPU at once: shallow form, deep form
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
   double ms_last = 0.0, ms_total = 0.0;
   uint64_t launches = 0;
   uint64_t camera_rays = 0;  // of the render launches since ptk_reset_stats: rows x width x samples, counted here
+  uint64_t batch_queries = 0;  // rays of the ray-batch launches since ptk_reset_stats that did not collect statistics
 };
 
 static std::string g_create_error;
@@ -1175,11 +1199,26 @@ static int launch_intersect(ptk_ctx* ctx, const float* d_rays, int32_t n, ptk_hi
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc = begin_timed(ctx, ev);
   if (rc) return rc;
-  dim3 grid((unsigned)std::min<int64_t>(((int64_t)n + kBlock - 1) / kBlock, 16384)), block(kBlock);  // 4 rounds of the resident waves
   auto kernel = ctx->deep_tree ? (stats ? intersect_kernel<true, true> : intersect_kernel<false, true>)
                                : (stats ? intersect_kernel<true, false> : intersect_kernel<false, false>);
-  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters);
+  // One round of resident waves, fewer for a batch that does not fill them (PTK_INTERSECT_GRID overrides).
+  int& resident = ctx->intersect_resident[ctx->deep_tree ? 1 : 0];
+  if (resident <= 0) {
+    int per_cu = 0, cus = 0;
+    PTK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
+    PTK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    resident = std::max(1, per_cu) * std::max(1, cus);
+    if (const char* e = getenv("PTK_INTERSECT_GRID")) resident = std::max(1, atoi(e));
+  }
+  // Rays per draw: two draws per wave for a small batch (so that all waves have work), kIntersectRunMax for a large one.
+  int64_t run = ((int64_t)n / (2 * (int64_t)resident) + kBlock - 1) / kBlock * kBlock;
+  run = std::min<int64_t>(std::max<int64_t>(run, kBlock), kIntersectRunMax);
+  if (const char* e = getenv("PTK_INTERSECT_RUN")) run = std::max(1, atoi(e));
+  dim3 grid((unsigned)std::min<int64_t>(((int64_t)n + run - 1) / run, resident)), block(kBlock);
+  PTK_HIP(hipMemsetAsync(ctx->d_counters + kIntersectQueueSlot, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, d_rays, n, d_hits, ctx->d_counters, (int)run);
   PTK_HIP(hipGetLastError());
+  if (!stats) ctx->batch_queries += (uint64_t)n;
   return end_timed(ctx, ev);
 }
 
@@ -1233,7 +1272,7 @@ int ptk_get_stats(ptk_ctx* ctx, ptk_stats* out)
   if (rc) return rc;
   unsigned long long c[kCounterSlots];
   PTK_HIP(hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-  out->camera_rays = ctx->camera_rays; out->segments = c[1]; out->queries = c[2]; out->box_tests = c[3]; out->prim_tests = c[4];
+  out->camera_rays = ctx->camera_rays; out->segments = c[1]; out->queries = c[2] + ctx->batch_queries; out->box_tests = c[3]; out->prim_tests = c[4];
   PTK_PHASE(if (getenv("PTK_PHASE_STATS")) {
     auto pct = [](unsigned long long lanes, unsigned long long iters) { return iters ? 100.0 * (double)lanes / (64.0 * (double)iters) : 0.0; };
     fprintf(stderr, "[ptk phases] descend: %llu wave-steps, %.1f%% lanes | leaves: %llu wave-steps, %.1f%% lanes at a leaf, %.1f%% at an inner node | advance: %llu wave-steps, %.1f%% lanes | leaf-loop passes: %llu (%.2f per leaf phase), %.1f%% lanes\n",
@@ -1258,6 +1297,7 @@ int ptk_reset_stats(ptk_ctx* ctx)
   ctx->ms_last = ctx->ms_total = 0.0;
   ctx->launches = 0;
   ctx->camera_rays = 0;
+  ctx->batch_queries = 0;
   return PTK_OK;
 }
 

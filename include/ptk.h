@@ -151,7 +151,10 @@ typedef struct {
 
 /* Scene layout facts after upload (for roofline accounting and tests) */
 typedef struct {
-  int32_t n_primitives, n_lights, n_nodes, max_depth, max_leaf_size, traversal_kind;
+  int32_t n_primitives, n_lights, n_nodes, max_depth, max_leaf_size;
+  int32_t traversal_kind;  /* which form of the render kernel the scene gets: 0 22-entry LDS stack, 1 27-entry LDS stack,
+                              2 whole scene in LDS, 3 22 entries + overflow words, 4 19 entries + material and light
+                              tables in LDS, 5 as 4 with overflow words */
   uint64_t node_bytes, prim_bytes, shading_bytes, texture_bytes;
   int32_t builder;         /* PTK_BUILDER_* that built the tree in use */
   int32_t tree_from_cache; /* 1: the host tree was read from the directory PTK_BVH_CACHE names */

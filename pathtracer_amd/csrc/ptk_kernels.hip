@@ -254,22 +254,28 @@ __device__ __forceinline__ void flush_counters(const Counters& c, unsigned long 
   }
 }
 
-// The kernel's forms (see ptk_layout.h: stack size, LDS, waves per SIMD): kFormShallow for trees of at most
-// kShallowTreeDepth levels, kFormDeep for deeper ones, kFormTiny for scenes whose whole tree and primitive records
-// fit a few KB of LDS (traversed from there).
-constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2, kFormSpill = 3;
+// The kernel's forms (see ptk_layout.h: stack size, LDS, waves per SIMD): kFormTiny for scenes whose whole tree and
+// primitive records fit a few KB of LDS (traversed from there); kFormShallowTables / kFormSpillTables (trees of at
+// most / more than kTablesTreeDepth levels) for scenes whose material and light tables fit beside a shorter stack
+// in LDS; otherwise kFormShallow for trees of at most kShallowTreeDepth levels and kFormSpill for deeper ones
+// (kFormDeep: the older all-LDS stack for those, kept for comparison).
+constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2, kFormSpill = 3, kFormShallowTables = 4, kFormSpillTables = 5;
 template <bool STATS, int FORM>
 __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
     SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra, f4* __restrict__ accum, f4* __restrict__ partial,
     unsigned long long* counters)
 {
   constexpr bool DEEP = FORM == kFormDeep, TINY = FORM == kFormTiny;
-  using LdsStack = ptk::LdsStack<DEEP ? kStackDepth : (TINY ? kStackDepthTiny : kStackDepthShallow),
-                                 FORM == kFormSpill ? kStackDepth - kStackDepthShallow : 0>;
-  using Mem = typename std::conditional<TINY, LdsMem, GlobalMem>::type;
+  constexpr bool TABLES = FORM == kFormShallowTables || FORM == kFormSpillTables;  // material and light tables in LDS
+  constexpr bool SPILL = FORM == kFormSpill || FORM == kFormSpillTables;           // stack entries beyond the LDS part
+  constexpr int kLdsDepth = DEEP ? kStackDepth : (TINY ? kStackDepthTiny : (TABLES ? kStackDepthTables : kStackDepthShallow));
+  using LdsStack = ptk::LdsStack<kLdsDepth, SPILL ? kStackDepth - kLdsDepth : 0>;
+  using Mem = typename std::conditional<TINY, LdsMem, typename std::conditional<TABLES, TablesMem, GlobalMem>::type>::type;
+  static_assert(!TABLES || kStackDepthTables > 19 || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes <= 5 * 1280,
+                "stack, pixel sums and tables share five LDS granules");
   constexpr int kSceneChunks = (kTinyNodes * sizeof(NodePair) + kTinyPrims * (sizeof(PrimRec) + sizeof(ShadeRec)) +
                                 kTinyMaterials * sizeof(MaterialRec) + kTinyLights * sizeof(LightRec)) / sizeof(f4);
-  __shared__ f4 lds_scene[TINY ? kSceneChunks : 1];
+  __shared__ f4 lds_scene[TINY ? kSceneChunks : (TABLES ? kTableBytes / sizeof(f4) : 1)];
   Mem mem;
   if constexpr (TINY) {
     // the workgroup's own copy of the scene, all of it but the texels (the __syncthreads below covers it)
@@ -285,6 +291,16 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     mem.shades = (const PTK_LDS_SPACE ShadeRec*)take(sc.shade, sc.n_prims, sizeof(ShadeRec) / sizeof(f4), kTinyPrims);
     mem.materials = (const PTK_LDS_SPACE MaterialRec*)take(sc.materials, sc.n_materials, sizeof(MaterialRec) / sizeof(f4), kTinyMaterials);
     mem.lights = (const PTK_LDS_SPACE LightRec*)take(sc.lights, sc.n_lights, sizeof(LightRec) / sizeof(f4), kTinyLights);
+  }
+  if constexpr (TABLES) {
+    // the workgroup's own copy of the light table and, behind it, the material table (ptk_upload_scene checked
+    // that both fit; the __syncthreads below covers the copy)
+    constexpr int kM = sizeof(MaterialRec) / sizeof(f4), kL = sizeof(LightRec) / sizeof(f4);
+    const int light_chunks = sc.n_lights * kL, material_chunks = sc.n_materials * kM;
+    for (int i = (int)threadIdx.x; i < light_chunks; i += kBlock) lds_scene[i] = reinterpret_cast<const f4*>(sc.lights)[i];
+    for (int i = (int)threadIdx.x; i < material_chunks; i += kBlock) lds_scene[light_chunks + i] = reinterpret_cast<const f4*>(sc.materials)[i];
+    mem.lights = (const PTK_LDS_SPACE LightRec*)lds_scene;
+    mem.materials = (const PTK_LDS_SPACE MaterialRec*)(lds_scene + light_chunks);
   }
   // read-only for the whole launch: the constant address space lets every use be a scalar load at that use
   const auto* consts = (const __attribute__((address_space(4))) DeviceConsts*)consts_global;
@@ -667,6 +683,8 @@ struct ptk_ctx {
   bool deep_tree = true;         // the tree has more than kShallowTreeDepth levels: the kernels' deep form runs
   bool tiny_scene = false;       // the tree and the primitive records fit the render kernel's LDS copy: its tiny form runs
   bool spill_stack = false;      // deep tree rendered with the shallow form's LDS stack plus overflow entries in private memory
+  bool lds_tables = false;       // the material and light tables fit beside a kStackDepthTables-entry stack: the render kernel's table forms run
+  bool tables_spill = false;     // ... and the tree has more than kTablesTreeDepth levels: with overflow entries
   bool have_scene_host = false;  // `host` still holds everything another context would need (ctx_upload_like)
   int32_t builder_asked = 0;
   HostScene host;  // kept for ptk_scene_info_get; texel pool is released after upload
@@ -857,6 +875,10 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
   ctx->tiny_scene = !ctx->deep_tree && h.max_depth <= kTinyTreeDepth && ctx->n_nodes <= kTinyNodes && h.n_prims <= kTinyPrims && h.n_prims > 0 &&
                     (int)h.materials.size() <= kTinyMaterials && (int)h.lights.size() <= kTinyLights &&
                     getenv("PTK_NO_TINY") == nullptr;
+  ctx->lds_tables = !ctx->tiny_scene && (ctx->spill_stack || !ctx->deep_tree) &&
+                    h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec) <= (size_t)kTableBytes &&
+                    getenv("PTK_NO_TABLES") == nullptr;
+  ctx->tables_spill = ctx->lds_tables && (h.max_depth > kTablesTreeDepth || getenv("PTK_FORCE_DEEP") != nullptr);
   if (!on_device) {
     if ((rc = upload(ctx, &ctx->d_nodes, h.nodes))) return rc;
     if ((rc = upload(ctx, &ctx->d_prims, h.prims))) return rc;
@@ -978,7 +1000,8 @@ int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
   out->n_nodes = ctx->n_nodes;
   out->max_depth = h.max_depth;
   out->max_leaf_size = h.max_leaf;
-  out->traversal_kind = 0;
+  out->traversal_kind = ctx->lds_tables ? (ctx->tables_spill ? kFormSpillTables : kFormShallowTables)
+                        : ctx->spill_stack ? kFormSpill : ctx->deep_tree ? kFormDeep : ctx->tiny_scene ? kFormTiny : kFormShallow;
   out->node_bytes = (uint64_t)ctx->n_nodes * sizeof(NodePair);
   out->prim_bytes = (uint64_t)std::max(h.n_prims, 1) * sizeof(PrimRec);
   out->shading_bytes = h.shade.size() * sizeof(ShadeRec) + h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec);
@@ -1115,7 +1138,9 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
   dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
-  auto kernel = ctx->spill_stack  ? (p->collect_stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>)
+  auto kernel = ctx->lds_tables   ? (ctx->tables_spill ? (p->collect_stats ? render_kernel<true, kFormSpillTables> : render_kernel<false, kFormSpillTables>)
+                                                        : (p->collect_stats ? render_kernel<true, kFormShallowTables> : render_kernel<false, kFormShallowTables>))
+                : ctx->spill_stack  ? (p->collect_stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>)
                 : ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
                 : ctx->tiny_scene ? (p->collect_stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>)
                                   : (p->collect_stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>);

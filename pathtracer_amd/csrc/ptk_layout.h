@@ -30,6 +30,18 @@ constexpr int kStackDepth = PTK_STACK_DEPTH;   // deep form: the largest stack
 constexpr int kStackDepthShallow = PTK_STACK_DEPTH_SHALLOW;  // (smaller in test builds, to exercise the overflow entries)
 constexpr int kMaxTreeDepth = kStackDepth - 2;  // the builder keeps trees this shallow (median splits if need be)
 constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
+// With three entries fewer (19: trees up to 17 levels without overflow entries) the same five granules also hold
+// the scene's material and light tables, 768 bytes of them: records that every path vertex reads and that all lanes
+// share, at three and seven vector loads each from global memory.  Scenes whose tables fit get these forms; the
+// entries beyond the nineteenth then live in the overflow words (ptk_kernels.hip, LdsStack).  Measured against the
+// 22-entry forms: +2.7 % on the 82k-triangle scene (20 levels: the overflow checks cost 3.9 %, the tables give 6.5 %),
+// +4.3 % on the 1.3M-triangle scene.
+#ifndef PTK_STACK_DEPTH_TABLES
+#define PTK_STACK_DEPTH_TABLES 19
+#endif
+constexpr int kStackDepthTables = PTK_STACK_DEPTH_TABLES;
+constexpr int kTablesTreeDepth = kStackDepthTables - 2;
+constexpr int kTableBytes = 768;
 // Tiny scenes (the Cornell box: 5 nodes, 12 triangles, 6 materials, 2 lights): the render kernel has a third form
 // that copies the whole scene except the texels into LDS when a workgroup starts and works from there - no
 // vector-memory instruction in the traversal, and none in shading but the texture fetches.  16 nodes (512 B) + 24

@@ -280,6 +280,14 @@ struct LdsMem {
   PTK_HD const PTK_LDS_SPACE MaterialRec& material(const SceneView&, uint32_t i) const { return materials[i]; }
   PTK_HD const PTK_LDS_SPACE LightRec& light(const SceneView&, int i) const { return lights[i]; }
 };
+// Nodes, primitive and shading records from global memory; the material and light tables (a few records that
+// every path vertex reads) from the workgroup's copy in LDS.
+struct TablesMem : GlobalMem {
+  const PTK_LDS_SPACE MaterialRec* materials;
+  const PTK_LDS_SPACE LightRec* lights;
+  PTK_HD const PTK_LDS_SPACE MaterialRec& material(const SceneView&, uint32_t i) const { return materials[i]; }
+  PTK_HD const PTK_LDS_SPACE LightRec& light(const SceneView&, int i) const { return lights[i]; }
+};
 #endif
 
 // Visit one inner node.  Straight-line code: whether a child is pushed, and whether the next node

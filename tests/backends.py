@@ -25,7 +25,7 @@ class GpuBackend:
         i = self.ctx.scene_info()
         return dict(n_nodes=i["n_nodes"], max_depth=i["max_depth"], max_leaf=i["max_leaf_size"],
                     n_lights=i["n_lights"], n_prims=i["n_primitives"], builder=i["builder"], tree_from_cache=i["tree_from_cache"],
-                    upload_ms=i["upload_ms"], device_build_ms=i["device_build_ms"])
+                    upload_ms=i["upload_ms"], device_build_ms=i["device_build_ms"], form=i["traversal_kind"])
 
     def intersect(self, rays):
         self.ctx.reset_stats()

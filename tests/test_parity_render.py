@@ -208,3 +208,40 @@ def test_tiny_scene_form_renders_the_same_frame(name, gpu_ctx, monkeypatch):
         assert abs(cnt_tiny[key] - cnt_plain[key]) <= 1e-4 * cnt_plain[key]
     for key in ("box_tests", "prim_tests"):
         assert abs(cnt_tiny_stats[key] - cnt_plain_stats[key]) <= 1e-4 * cnt_plain_stats[key]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mesh", "sky", "mirror_tex"])
+def test_table_forms_render_the_same_frame(name, gpu_ctx, monkeypatch):
+    """Scenes whose material and light tables fit 768 bytes are rendered by the kernel forms that keep those tables
+    in LDS beside a 19-entry stack (ptk_layout.h: kTableBytes).  The frame must not depend on that: PTK_NO_TABLES=1
+    at upload time selects the forms that fetch them from global memory, PTK_FORCE_DEEP=1 the forms with overflow
+    stack entries, and a scene with too many materials for the tables falls back by itself."""
+    import copy
+    sd = scene(name)
+    monkeypatch.setenv("PTK_NO_TINY", "1")  # (two of the scenes are small enough for the whole-scene-in-LDS form)
+    with_tables = GpuBackend(gpu_ctx, sd)
+    assert with_tables.info()["form"] in (4, 5), with_tables.info()
+    frames = {"tables": with_tables.render(64, 3, seed=9, collect_stats=False)}
+    monkeypatch.setenv("PTK_FORCE_DEEP", "1")
+    b = GpuBackend(gpu_ctx, sd)
+    assert b.info()["form"] == 5
+    frames["tables, overflow stack"] = b.render(64, 3, seed=9, collect_stats=False)
+    monkeypatch.delenv("PTK_FORCE_DEEP")
+    monkeypatch.setenv("PTK_NO_TABLES", "1")
+    b = GpuBackend(gpu_ctx, sd)
+    assert b.info()["form"] in (0, 3)
+    frames["global memory"] = b.render(64, 3, seed=9, collect_stats=False)
+    monkeypatch.delenv("PTK_NO_TABLES")
+    crowded = copy.deepcopy(sd)
+    crowded.materials = list(crowded.materials) + [crowded.materials[0]] * 16  # unused, but the table no longer fits
+    b = GpuBackend(gpu_ctx, crowded)
+    assert b.info()["form"] in (0, 3)
+    frames["too many materials"] = b.render(64, 3, seed=9, collect_stats=False)
+    img0, cnt0 = frames["tables"]
+    for what, (img, cnt) in frames.items():
+        differing = np.any(np.abs(img0 - img) > 1e-5 * np.maximum(np.abs(img0), np.abs(img)) + 1e-7, axis=-1).mean()
+        assert differing <= 0.02, (what, differing)
+        assert abs(img0.mean() - img.mean()) <= 1e-3 * img0.mean(), what
+        for key in ("queries", "segments"):
+            assert abs(cnt0[key] - cnt[key]) <= 1e-4 * cnt0[key], (what, key)

@@ -90,15 +90,18 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
 #endif
+#ifndef PTK_STACK_ROOM
+#define PTK_STACK_ROOM 8  // steps that the descend loop runs unchecked after one look at every lane's stack height
+#endif
 // OVER > 0: the stack may grow OVER entries beyond its DEPTH entries of LDS.  Those entries live in the lane's
 // private memory (`over`, a few words of scratch).  A traversal stack holds one entry per level at which BOTH
-// children were hit and the far one still waits, so even in a 25-level tree more than twenty pending entries is a
-// rarity; every operation first asks, for the whole wave at once (one compare and a scalar branch), whether any
-// lane is that far up, and only then takes the path that looks at each entry's level.  Even that question is asked
-// rarely: `room` counts how many more pushes every lane of the wave can certainly take (refresh(), one ballot, grants
-// kRoom of them when no lane is within kRoom entries of the end of its LDS part; the caller takes one off per
-// wave-wide step), and while it is positive no operation checks anything.  This is what lets deep trees run with the
-// LDS footprint - and so the resident waves - of shallow ones.
+// children were hit and the far one still waits, so even in a 25-level tree more than nineteen pending entries is a
+// rarity.  Every operation of this type first asks, for the whole wave at once (one compare and a scalar branch),
+// whether any lane is that far up, and only then takes the path that looks at each entry's level.  The descend
+// loop does better: roomy() tells it (one ballot) that no lane is within kRoom entries of the end of its LDS
+// part, and it then runs kRoom steps on unchecked(), the same stack seen as a plain LDS stack whose operations
+// check nothing.  This is what lets deep trees run with the LDS footprint - and so the resident waves - of
+// shallow ones.
 template <int DEPTH, int OVER = 0>
 struct LdsStack {
   static constexpr int kDepth = DEPTH;
@@ -114,20 +117,23 @@ struct LdsStack {
                             // object, so that top and base stay in registers; volatile, so that it stays memory and is
                             // not turned into OVER more live registers)
   static constexpr int kOver = OVER > 0 ? OVER : 1;
-  static constexpr int kRoom = 8;
-  int room;  // wave-uniform: every lane's top is at or below base + DEPTH - 2 - room (meaningless when it is <= 0)
+  static constexpr int kRoom = PTK_STACK_ROOM;
+  static_assert(OVER == 0 || DEPTH - 2 - kRoom >= 1, "a stack with overflow entries needs room for the unchecked steps");
+  using Unchecked = LdsStack<DEPTH, 0>;
   __device__ __forceinline__ void attach(uint32_t* array, int lane, volatile uint32_t* over_entries = nullptr)
   {
     base = top = (Word*)array + (PTK_STACK_LANE_MAJOR ? lane * DEPTH : lane);
     over = over_entries;
-    room = 0;
   }
-  // To be called with all lanes of the wave active, before a wave-wide step; the caller then takes one off `room`.
-  __device__ __forceinline__ void refresh()
+  // True when every lane of the wave can take kRoom more pushes (one per step, plus the scratch entry above the top)
+  // inside its LDS part.  To be called with all lanes of the wave active.
+  __device__ __forceinline__ bool roomy() const { return OVER == 0 || __ballot(top > base + (DEPTH - 2 - kRoom)) == 0ull; }
+  __device__ __forceinline__ Unchecked unchecked() const
   {
-    if (OVER > 0 && room <= 0) room = __ballot(top > base + (DEPTH - 2 - kRoom)) == 0ull ? kRoom : 0;
+    Unchecked u;
+    u.top = top; u.base = base; u.over = nullptr;
+    return u;
   }
-  __device__ __forceinline__ void stepped() { if (OVER > 0) room -= 1; }
   __device__ __forceinline__ void reset() { top = base; *top = (uint32_t)kTravDone; }
   // entry at address p, wherever it lives
   __device__ __forceinline__ uint32_t read_at(const Word* p) const
@@ -147,7 +153,7 @@ struct LdsStack {
   // true when some lane's entry at `p` or above may lie outside LDS
   __device__ __forceinline__ bool any_beyond(const Word* p) const
   {
-    return OVER > 0 && room <= 0 && __builtin_expect(__ballot(p >= base + DEPTH) != 0ull, 0);
+    return OVER > 0 && __builtin_expect(__ballot(p >= base + DEPTH) != 0ull, 0);
   }
   __device__ __forceinline__ void push(uint32_t v)
   {
@@ -385,17 +391,30 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     // second leaf.  The leaf phase then intersects the leaf put aside and the one the lane stands at.
     // (Descending past a leaf uses a closest-hit distance that is not up to date, which costs a few extra
     // node visits and never a wrong answer.  Holding one leaf: +13 % frame rate; holding two: -6 %.)
-    for (;;) {
-      st.refresh();
-      if (trav_at_leaf(ps.tr) && held == kTravDone) { held = ps.tr.node; ps.tr.node = (int32_t)st.pop(); }
+    // One step of the descend loop on stack `s` (the lane's stack, or its unchecked view); true: leave the loop.
+    auto descend_step = [&](auto& s) -> bool {
+      using S = typename std::remove_reference<decltype(s)>::type;
+      if (trav_at_leaf(ps.tr) && held == kTravDone) { held = ps.tr.node; ps.tr.node = (int32_t)s.pop(); }
       const bool want = trav_at_inner(ps.tr);
       const int n_want = __popcll(__ballot(want));
       // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no leaf is held
       const bool any_held = __ballot(held != kTravDone) != 0ull;
-      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
+      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) return true;  // evaluated eagerly: one branch instead of three
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
-      if (want) trav_inner<LdsStack, STATS, Mem>(ps.tr, st, sc, cnt, mem);
-      st.stepped();
+      if (want) trav_inner<S, STATS, Mem>(ps.tr, s, sc, cnt, mem);
+      return false;
+    };
+    for (;;) {
+      if (SPILL && st.roomy()) {
+        auto fast = st.unchecked();
+        bool leave = false;
+#pragma nounroll
+        for (int k = 0; k < LdsStack::kRoom && !leave; k++) leave = descend_step(fast);
+        st.top = fast.top;
+        if (leave) break;
+      } else if (descend_step(st)) {
+        break;
+      }
     }
     PTK_PHASE_CLOCK(0)
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)

@@ -1248,9 +1248,17 @@ static int launch_intersect(ptk_ctx* ctx, const float* d_rays, int32_t n, ptk_hi
   // One round of resident waves, fewer for a batch that does not fill them (PTK_INTERSECT_GRID overrides).
   int& resident = ctx->intersect_resident[ctx->deep_tree ? 1 : 0];
   if (resident <= 0) {
-    int per_cu = 0, cus = 0;
+    int per_cu = 0, cus = 0, lds_per_cu = 0;
     PTK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0));
     PTK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    // LDS is handed out in granules of 1280 bytes here, which the occupancy query does not know (it answers 27 where
+    // 25 workgroups fit); the two extra workgroups per CU would run after the others have ended.
+    hipFuncAttributes fa;
+    PTK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)));
+    PTK_HIP(hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, ctx->device));
+    constexpr int kLdsGranule = 1280;
+    const int lds = ((int)fa.sharedSizeBytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+    if (lds > 0 && lds_per_cu > 0) per_cu = std::min(per_cu, lds_per_cu / lds);
     resident = std::max(1, per_cu) * std::max(1, cus);
     if (const char* e = getenv("PTK_INTERSECT_GRID")) resident = std::max(1, atoi(e));
   }

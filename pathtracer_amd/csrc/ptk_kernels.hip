@@ -71,6 +71,7 @@ constexpr size_t kStaticScratchBytes = (size_t)128 << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 constexpr int kCounterSlots = 24;  // 0-4 the ptk_stats counters, 8-14 wave-phase counters and 16-20 phase clocks of a PTK_PHASE_STATS build, 22 the ray-batch kernel's work counter
 constexpr int kIntersectQueueSlot = 22;
+constexpr size_t kUnitQueueBytes = 8 * 32 * sizeof(unsigned int);  // eight counters, 128 bytes apart
 constexpr int kIntersectRunMax = 1024;  // most rays a wave draws from the work counter at a time
 
 // A build with -DPTK_PHASE_STATS makes instrumented launches also count, per wave, how often each
@@ -204,7 +205,8 @@ struct RenderArgs {
   int32_t sample_first, sample_stride;
   int32_t row_begin, row_end;
   int32_t tiles_x, n_tiles;
-  int32_t chunks;  // workgroups per tile; each takes every chunks-th sample
+  int32_t chunks;  // work units per tile; each takes every chunks-th sample
+  int32_t persistent;  // 1: the launch has fewer workgroups than work units, and a workgroup draws further units from unit_queue
   // Rows of the launch -> rows of the image.  A launch covers `rows` rows (a multiple of the tile
   // height, the image edge is cut off by row_end): either rows [row_begin, row_end) of the image, or
   // the interleaved bands band_first, band_first + band_stride, ... of band_rows rows each.
@@ -269,7 +271,7 @@ constexpr int kFormShallow = 0, kFormDeep = 1, kFormTiny = 2, kFormSpill = 3, kF
 template <bool STATS, int FORM>
 __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW) void render_kernel(
     SceneView sc, const DeviceConsts* __restrict__ consts_global, RenderArgs ra, f4* __restrict__ accum, f4* __restrict__ partial,
-    unsigned long long* counters)
+    unsigned long long* counters, unsigned int* unit_queue)
 {
   constexpr bool DEEP = FORM == kFormDeep, TINY = FORM == kFormTiny;
   constexpr bool TABLES = FORM == kFormShallowTables || FORM == kFormSpillTables;  // material and light tables in LDS
@@ -321,13 +323,25 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   // Virtual id -> (tile, sample chunk).  An XCD's consecutive workgroups are the chunks of one
   // tile, then the next tile of the same tile row; tile rows are dealt to the XCDs round-robin
   // (row r -> XCD r % 8) so that every XCD sees the same mix of cheap and expensive image regions.
-  int virt = xcd_remap((int)blockIdx.x, ra.n_tiles * ra.chunks);
+  // A work unit is one (tile, chunk) pair.  With one workgroup per unit the hardware hands them out in order, one
+  // XCD after the other, and a unit that waits for a free slot on its XCD holds up the units behind it on the
+  // others.  A persistent launch has as many workgroups as fit the GPU at once; each starts on the unit of its own
+  // number and then draws the next units of ITS XCD's share from that XCD's counter (unit_queue, one cache line
+  // each, zeroed before the launch).  Which workgroup renders a unit does not change what the unit computes or
+  // where it writes.
+  const int lane = threadIdx.x;
+  const int n_units = ra.n_tiles * ra.chunks, xcd = (int)blockIdx.x & 7;
+  const int units_here = (n_units >> 3) + (xcd < (n_units & 7) ? 1 : 0);               // this XCD's share
+  const int groups_here = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);  // workgroups of the launch on this XCD
+  Counters cnt = {0, 0, 0, 0, 0};
+  constexpr bool kWaveCounts = !DEEP;
+  unsigned long long wave_segments = 0, wave_queries = 0;
+  for (int unit = (int)blockIdx.x >> 3; unit < units_here;) {
+  int virt = xcd_remap(xcd + 8 * unit, n_units);
   int tile = virt / ra.chunks, chunk = virt - tile * ra.chunks;
   int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
   ty = interleave_rows(ty, ra.n_tiles / ra.tiles_x);
-  const int lane = threadIdx.x;
 
-  Counters cnt = {0, 0, 0, 0, 0};
   PathParams pp;
   pp.x0 = tx * kTile; pp.y0 = launch_row_to_image_row(ra, ty * kTile);
   pp.slot_bits = 6; pp.row_bits = 3;
@@ -350,8 +364,6 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   // (a ballot and a scalar add) instead of in a register of every lane: the per-lane counts of `cnt` are left
   // unread in this kernel, so the compiler drops them.  Camera rays are counted by the host (rows x width x samples).
   // (The deep-tree form has the registers and is 1 % faster with the per-lane counts, so it keeps them.)
-  constexpr bool kWaveCounts = !DEEP;
-  unsigned long long wave_segments = 0, wave_queries = 0;
   auto refill = [&](bool need) {
     for (;;) {
       unsigned long long m = __ballot(need);
@@ -484,6 +496,12 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       size_t i = ((size_t)chunk * (size_t)ra.rows + r) * (size_t)cam.width + (size_t)px;
       partial[i] = a;
     }
+  }
+  if (!ra.persistent) break;
+  unsigned int drawn = 0u;
+  if (lane == 0) drawn = atomicAdd(unit_queue + xcd * 32, 1u);
+  unit = groups_here + (int)__builtin_amdgcn_readfirstlane(drawn);
+  __syncthreads();  // the pixel sums are zeroed again at the top
   }
   {
     const unsigned long long boxes = STATS ? wave_sum(cnt.box_tests) : 0ull, prims = STATS ? wave_sum(cnt.prim_tests) : 0ull;
@@ -735,6 +753,7 @@ struct ptk_ctx {
   size_t stage_capacity = 0;  // in rays
   // counters and timing
   unsigned long long* d_counters = nullptr;
+  unsigned int* d_unit_queue = nullptr;  // the render kernel's work-unit counters, one cache line per XCD
   int intersect_resident[2] = {0, 0};  // waves of the ray-batch kernel that fit the GPU at once: shallow form, deep form
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
   double ms_last = 0.0, ms_total = 0.0;
@@ -961,6 +980,7 @@ int ptk_create(int device, ptk_ctx** out)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_counters, kCounterSlots * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_counters, 0, kCounterSlots * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_unit_queue, kUnitQueueBytes);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_consts, sizeof(DeviceConsts));
   // with `device` current: the address of this device's copy of the static scratch array
   if (e == hipSuccess) e = hipGetSymbolAddress((void**)&ctx->d_static_scratch, HIP_SYMBOL(scratch));
@@ -985,6 +1005,7 @@ int ptk_destroy(ptk_ctx* ctx)
   if (ctx->d_stage_rays) (void)hipFree(ctx->d_stage_rays);
   if (ctx->d_stage_hits) (void)hipFree(ctx->d_stage_hits);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_unit_queue) (void)hipFree(ctx->d_unit_queue);
   if (ctx->d_consts) (void)hipFree(ctx->d_consts);
   for (auto& pr : ctx->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto& pr : ctx->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -1156,14 +1177,21 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   std::pair<hipEvent_t, hipEvent_t> ev;
   int rc = static_scratch ? PTK_OK : begin_timed(ctx, ev);  // timing events may have to be created
   if (rc) return rc;
-  dim3 grid((unsigned)(ra.n_tiles * ra.chunks)), block(kBlock);
+  // More units than fit the GPU at once: as many workgroups as fit, which draw the units from per-XCD counters.
+  const int64_t n_units = (int64_t)ra.n_tiles * ra.chunks;
+  const int64_t resident = 256 * 4 * (int64_t)(ctx->deep_tree && !ctx->spill_stack ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
+  // (+0.2-0.4 % on the mesh scenes; the Cornell box's whole-scene-in-LDS form loses as much and keeps one workgroup per unit)
+  ra.persistent = n_units > resident && !ctx->tiny_scene && getenv("PTK_NO_PERSISTENT") == nullptr ? 1 : 0;
+  if (ra.persistent) PTK_HIP(hipMemsetAsync(ctx->d_unit_queue, 0, kUnitQueueBytes, ctx->stream));
+  dim3 grid((unsigned)(ra.persistent ? resident : n_units)), block(kBlock);
   auto kernel = ctx->lds_tables   ? (ctx->tables_spill ? (p->collect_stats ? render_kernel<true, kFormSpillTables> : render_kernel<false, kFormSpillTables>)
                                                         : (p->collect_stats ? render_kernel<true, kFormShallowTables> : render_kernel<false, kFormShallowTables>))
                 : ctx->spill_stack  ? (p->collect_stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>)
                 : ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
                 : ctx->tiny_scene ? (p->collect_stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>)
                                   : (p->collect_stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>);
-  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters);
+  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters,
+                     ctx->d_unit_queue);
   PTK_HIP(hipGetLastError());
   if (static_scratch) ctx->launches++;
   else rc = end_timed(ctx, ev);

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from pathtracer_amd import native
+from pathtracer_amd import native, scenes
 from tests import parity
 from tests.backends import BACKENDS, GpuBackend, make_backend, scene
 
@@ -245,3 +245,19 @@ def test_table_forms_render_the_same_frame(name, gpu_ctx, monkeypatch):
         assert abs(img0.mean() - img.mean()) <= 1e-3 * img0.mean(), what
         for key in ("queries", "segments"):
             assert abs(cnt0[key] - cnt[key]) <= 1e-4 * cnt0[key], (what, key)
+
+
+@pytest.mark.gpu
+def test_persistent_launch_renders_the_same_bits(gpu_ctx, monkeypatch):
+    """A frame with more work units (tile x sample chunk) than fit the GPU at once is rendered by as many workgroups as
+    fit, which draw the units from counters.  Which workgroup renders a unit changes nothing: the frame is the one that a
+    launch with one workgroup per unit (PTK_NO_PERSISTENT=1) gives, bit for bit, and so is a second persistent launch."""
+    sd = scenes.cornell_with_mesh(4, 256, 256)  # 1 024 tiles x 8 chunks of 16 samples = 8 192 units
+    b = GpuBackend(gpu_ctx, sd)
+    first, cnt_first = b.render(128, 3, seed=21, collect_stats=False)
+    again, _ = b.render(128, 3, seed=21, collect_stats=False)
+    monkeypatch.setenv("PTK_NO_PERSISTENT", "1")
+    plain, cnt_plain = b.render(128, 3, seed=21, collect_stats=False)
+    assert np.array_equal(first, again)
+    assert np.array_equal(first, plain)
+    assert cnt_first == cnt_plain

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       partial[i] = a;
     }
   }
-  if (!ra.persistent) break;
+  if (TINY || !ra.persistent) break;  // (the tiny form is never launched persistent: its code is better without the loop)
   unsigned int drawn = 0u;
   if (lane == 0) drawn = atomicAdd(unit_queue + xcd * 32, 1u);
   unit = groups_here + (int)__builtin_amdgcn_readfirstlane(drawn);

@@ -90,18 +90,22 @@ def test_frame_plan_covers_every_sample_once():
         parallel.frame_plan("spp", 2, 2, 4, 16)
 
 
-def _gpu_worker(rank, world, port, split, spp, bounces, out_path):
+def _gpu_worker(rank, world, port, split, spp, bounces, out_path, one_gpu=False):
     import torch
     import torch.distributed as dist
     from pathtracer_amd import native
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    device = 0 if one_gpu else rank
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    if one_gpu:  # RCCL refuses two ranks on one device: the collective goes through gloo
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     sd = scenes.cornell_with_mesh(3, 96, 72)
-    ctx = native.Context(rank)
+    ctx = native.Context(device)
     ctx.upload_scene(sd)
     ctx.set_camera(sd.camera)
     accum = torch.zeros((72, 96, 4), dtype=torch.float32, device=dev)
@@ -130,18 +134,12 @@ def _device_count():
         return 0
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
-@pytest.mark.parametrize("split", ["tile", "spp"])
-def test_two_gpus_reproduce_the_single_gpu_frame(split, tmp_path):
-    """The real N > 1 sequence: libptk renders into a torch tensor bound as the accumulation buffer on each
-    GPU, then one RCCL collective merges the frame on rank 0.  Tile split: bit-identical to one GPU rendering
-    the same bands; spp split: equal up to fp32 summation order."""
+def _two_ranks_against_one(split, tmp_path, one_gpu):
     import torch.multiprocessing as mp
     from pathtracer_amd import native
     world, spp, bounces = 2, 32, 3
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_gpu_worker, args=(world, _free_port(), split, spp, bounces, out), nprocs=world, join=True)
+    mp.spawn(_gpu_worker, args=(world, _free_port(), split, spp, bounces, out, one_gpu), nprocs=world, join=True)
     merged = np.load(out)
     sd = scenes.cornell_with_mesh(3, 96, 72)
     ctx = native.Context(0)
@@ -164,3 +162,21 @@ def test_two_gpus_reproduce_the_single_gpu_frame(split, tmp_path):
     if split == "tile":
         assert np.array_equal(mean, single)
     assert np.allclose(mean, single, rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("split", ["tile", "spp"])
+def test_two_gpus_reproduce_the_single_gpu_frame(split, tmp_path):
+    """The real N > 1 sequence: libptk renders into a torch tensor bound as the accumulation buffer on each
+    GPU, then one RCCL collective merges the frame on rank 0.  Tile split: bit-identical to one GPU rendering
+    the same bands; spp split: equal up to fp32 summation order."""
+    _two_ranks_against_one(split, tmp_path, one_gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", ["tile", "spp"])
+def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_frame(split, tmp_path):
+    """The same sequence on a box with one GPU: two processes, each with its own libptk context on GPU 0 and its own
+    bound accumulation tensor, the merge through gloo.  Everything but the RCCL transport is what two GPUs would run."""
+    _two_ranks_against_one(split, tmp_path, one_gpu=True)

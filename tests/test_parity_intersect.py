@@ -198,3 +198,39 @@ def test_origins_far_from_the_scene(backend, scene_name, factor, request):
     rec = parity.check_hit_records(ref, got)
     # hit points: the product d * distance carries a few fp32 ulps of the distance travelled (up to 4200 units)
     assert rec["point"] < 4e-8 * 14.0 * factor and rec["material_mismatch"] == 0, rec
+
+
+@pytest.mark.gpu
+def test_batch_sizes_around_the_draw_boundaries(gpu_ctx, monkeypatch):
+    """The ray-batch kernel's waves draw runs of rays from a counter (first run: the wave's own number).  Every ray of
+    a batch must be answered exactly once whatever the batch size does to the run length, the number of workgroups
+    and the last, partial run: the records of a batch cut into pieces are those of the whole batch, and a forced
+    short run length and a forced small grid change nothing."""
+    from tests.backends import GpuBackend
+    sd = scene("mesh")
+    b = GpuBackend(gpu_ctx, sd)
+    rays = _f32_rays(np.concatenate([raygen.interior_rays(150000, 7), raygen.camera_like_rays(50000, 8)]))
+    whole, _ = b.intersect(rays)
+    assert (whole["hit"] == 1).mean() > 0.5
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 4097, 65535, 65537, 131073):
+        part, _ = b.intersect(rays[:n])
+        for key in ("hit", "id", "t", "point", "normal", "uv", "material", "inside"):
+            assert np.array_equal(part[key], whole[key][:n]), (n, key)
+    for run in ("64", "192", "7"):  # read at every launch
+        monkeypatch.setenv("PTK_INTERSECT_RUN", run)
+        part, _ = b.intersect(rays[:50001])
+        monkeypatch.delenv("PTK_INTERSECT_RUN")
+        for key in ("hit", "id", "t"):
+            assert np.array_equal(part[key], whole[key][:50001]), (run, key)
+    from pathtracer_amd import native
+    for grid in ("7", "100000"):  # read when a context launches its first batch
+        monkeypatch.setenv("PTK_INTERSECT_GRID", grid)
+        ctx = native.Context(0)
+        try:
+            other = GpuBackend(ctx, sd)
+            part, _ = other.intersect(rays[:50001])
+        finally:
+            ctx.close()
+            monkeypatch.delenv("PTK_INTERSECT_GRID")
+        for key in ("hit", "id", "t"):
+            assert np.array_equal(part[key], whole[key][:50001]), (grid, key)

@@ -101,6 +101,9 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 // words, lanes kStackDepth words apart - an odd number, so lanes at the same level still fall into different
 // banks): moving the top is +-4 bytes, which fits an instruction's inline constant; level-major
 // (stack[level][lane]) needs +-256 and two registers to hold those.
+#ifndef PTK_STEAL_UNITS
+#define PTK_STEAL_UNITS 1  // persistent render launches: a workgroup whose XCD has no units left takes other XCDs' units
+#endif
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
 #endif
@@ -343,9 +346,11 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   // each, zeroed before the launch).  Which workgroup renders a unit does not change what the unit computes or
   // where it writes.
   const int lane = threadIdx.x;
-  const int n_units = ra.n_tiles * ra.chunks, xcd = (int)blockIdx.x & 7;
-  const int units_here = (n_units >> 3) + (xcd < (n_units & 7) ? 1 : 0);               // this XCD's share
-  const int groups_here = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);  // workgroups of the launch on this XCD
+  const int n_units = ra.n_tiles * ra.chunks;
+  int xcd = (int)blockIdx.x & 7;  // the XCD whose share the current unit is from (the wave's own, until that runs out)
+  auto units_of = [&](int x) { return (n_units >> 3) + (x < (n_units & 7) ? 1 : 0); };                 // an XCD's share
+  auto groups_of = [&](int x) { return ((int)gridDim.x >> 3) + (x < ((int)gridDim.x & 7) ? 1 : 0); };  // its workgroups of the launch
+  int units_here = units_of(xcd);
   Counters cnt = {0, 0, 0, 0, 0};
   constexpr bool kWaveCounts = !DEEP;
   unsigned long long wave_segments = 0, wave_queries = 0;
@@ -515,9 +520,16 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     }
   }
   if (TINY || !ra.persistent) break;  // (the tiny form is never launched persistent: its code is better without the loop)
-  unsigned int drawn = 0u;
-  if (lane == 0) drawn = atomicAdd(unit_queue + xcd * 32, 1u);
-  unit = groups_here + (int)__builtin_amdgcn_readfirstlane(drawn);
+  // the next unit of this XCD's share; when that has run out, of the next XCD's that has units left (the shares are
+  // equal in units, not in work: the XCDs with the cheaper tiles would otherwise stand idle at the end of a launch)
+  for (int tries = 0; tries < 8; tries++) {
+    unsigned int drawn = 0u;
+    if (lane == 0) drawn = atomicAdd(unit_queue + xcd * 32, 1u);
+    unit = groups_of(xcd) + (int)__builtin_amdgcn_readfirstlane(drawn);
+    units_here = units_of(xcd);
+    if (unit < units_here || !PTK_STEAL_UNITS) break;
+    xcd = (xcd + 1) & 7;
+  }
   __syncthreads();  // the pixel sums are zeroed again at the top
   }
   {

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   Counters cnt = {0, 0, 0, 0, 0};
   constexpr bool kWaveCounts = !DEEP;
   unsigned long long wave_segments = 0, wave_queries = 0;
+  unsigned long long wave_boxes = 0, wave_prims = 0;  // STATS: the lanes' 32-bit test counts, folded in after every unit
   for (int unit = (int)blockIdx.x >> 3; unit < units_here;) {
   int virt = xcd_remap(xcd + 8 * unit, n_units);
   int tile = virt / ra.chunks, chunk = virt - tile * ra.chunks;
@@ -497,7 +498,17 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     PTK_PHASE_CLOCK(4)
     __builtin_amdgcn_s_setprio(PTK_PRIO_DESCEND);
   }
-  PTK_PHASE(ph[7] = (uint32_t)wave_sum(cnt.leaf_iterations);)
+  PTK_PHASE(ph[7] = (uint32_t)wave_sum(cnt.leaf_iterations); cnt.leaf_iterations = 0;)
+  if (STATS) {  // per unit, so that a lane's 32-bit counts cannot wrap however many units a persistent workgroup draws
+    wave_boxes += wave_sum(cnt.box_tests);
+    wave_prims += wave_sum(cnt.prim_tests);
+    cnt.box_tests = cnt.prim_tests = 0;
+  }
+  if (!kWaveCounts) {
+    wave_segments += wave_sum(cnt.segments);
+    wave_queries += wave_sum(cnt.queries);
+    cnt.segments = cnt.queries = 0;
+  }
   PTK_PHASE(if (STATS && (threadIdx.x & 63) == 0) {
     for (int k = 0; k < 8; k++) atomicAdd(&counters[8 + k], (unsigned long long)ph[k]);
     for (int k = 0; k < 5; k++) atomicAdd(&counters[16 + k], tph[k]);
@@ -533,8 +544,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   __syncthreads();  // the pixel sums are zeroed again at the top
   }
   {
-    const unsigned long long boxes = STATS ? wave_sum(cnt.box_tests) : 0ull, prims = STATS ? wave_sum(cnt.prim_tests) : 0ull;
-    if (!kWaveCounts) { wave_segments = wave_sum(cnt.segments); wave_queries = wave_sum(cnt.queries); }
+    const unsigned long long boxes = wave_boxes, prims = wave_prims;
     if (lane == 0) {
       atomicAdd(&counters[1], wave_segments);
       atomicAdd(&counters[2], wave_queries);

@@ -203,6 +203,29 @@ struct LdsStack {
   }
 };
 
+// The two vectors of a path that only wait while its shadow ray is traced (ParkInState in ptk_shade.h), in LDS: word k
+// of lane l at base[k * 64 + l].  Kept in the path state they are live through every traversal loop, and at six
+// waves per SIMD that is six registers the compiler otherwise finds in scratch memory (7 spilled dwords -> 2).  Measured:
+// the 1536 bytes have to come out of the traversal stacks (13 LDS entries per lane instead of 19), and that costs more
+// than the spills did: -0.7 % on the 82k-triangle scene, -1.2 % on the 1.3M-triangle scene, -0.2 % on the glass scene.
+// Hence off; -DPTK_PARK=1 -DPTK_STACK_DEPTH_TABLES=13 -DPTK_STACK_DEPTH_SHALLOW=16 -DPTK_STACK_ROOM=4 builds it.
+#ifndef PTK_PARK
+#define PTK_PARK 0
+#endif
+struct LdsPark {
+  PTK_LDS_SPACE float* at;  // this lane's word 0
+  __device__ __forceinline__ void store(PathState&, v3 pending, v3 next_d) const
+  {
+    at[0] = pending.x; at[kBlock] = pending.y; at[2 * kBlock] = pending.z;
+    at[3 * kBlock] = next_d.x; at[4 * kBlock] = next_d.y; at[5 * kBlock] = next_d.z;
+  }
+  __device__ __forceinline__ void load(const PathState&, v3& pending, v3& next_d) const
+  {
+    pending = V3(at[0], at[kBlock], at[2 * kBlock]);
+    next_d = V3(at[3 * kBlock], at[4 * kBlock], at[5 * kBlock]);
+  }
+};
+
 // Per-pixel radiance sums of a tile, in LDS.  Two lanes can finish paths of the same pixel in the
 // same step, hence the atomic add (ds_add_f32).
 struct LdsAccum {
@@ -295,8 +318,10 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   constexpr int kLdsDepth = DEEP ? kStackDepth : (TINY ? kStackDepthTiny : (TABLES ? kStackDepthTables : kStackDepthShallow));
   using LdsStack = ptk::LdsStack<kLdsDepth, SPILL ? kStackDepth - kLdsDepth : 0>;
   using Mem = typename std::conditional<TINY, LdsMem, typename std::conditional<TABLES, TablesMem, GlobalMem>::type>::type;
-  static_assert(!TABLES || kStackDepthTables > 19 || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes <= 5 * 1280,
-                "stack, pixel sums and tables share five LDS granules");
+  constexpr bool PARK = PTK_PARK && !DEEP && !TINY;  // the waiting vectors of a path in LDS (LdsPark)
+  static_assert(!TABLES || kStackDepthTables > (PARK ? 13 : 19) || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes + (PARK ? kParkBytes : 0) <= 5 * 1280,
+                "stack, pixel sums, tables (and parked vectors) share five LDS granules");
+  using Park = typename std::conditional<PARK, LdsPark, ParkInState>::type;
   constexpr int kSceneChunks = (kTinyNodes * sizeof(NodePair) + kTinyPrims * (sizeof(PrimRec) + sizeof(ShadeRec)) +
                                 kTinyMaterials * sizeof(MaterialRec) + kTinyLights * sizeof(LightRec)) / sizeof(f4);
   __shared__ f4 lds_scene[TINY ? kSceneChunks : (TABLES ? kTableBytes / sizeof(f4) : 1)];
@@ -332,6 +357,9 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   const FlagView& fl = *(const FlagView*)&consts->fl;
   __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ float lds_sum[3 * kBlock];  // r, g, b sums of the tile's 64 pixel slots
+  __shared__ float lds_park[PARK ? kParkBytes / sizeof(float) : 1];
+  Park park;
+  if constexpr (PARK) park.at = (PTK_LDS_SPACE float*)lds_park + threadIdx.x;
   LdsStack st;
   volatile uint32_t stack_over[LdsStack::kOver];
   st.attach(lds_stack, (int)threadIdx.x, stack_over);
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
       bool goes_on = false;
       if (lit) {
-        goes_on = !path_consume_shadow(ps, st, sc, fl, pp, cnt);
+        goes_on = !path_consume_shadow(ps, st, sc, fl, pp, cnt, park);
         if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
       }
       if (kWaveCounts) {
@@ -481,7 +509,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
       bool goes_on = false;
       if (shade) {
-        goes_on = !path_shade<LdsStack, Mem>(ps, st, sc, fl, pp, cnt, mem);
+        goes_on = !path_shade<LdsStack, Mem, Park>(ps, st, sc, fl, pp, cnt, mem, park);
         if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
       }
       if (kWaveCounts) {

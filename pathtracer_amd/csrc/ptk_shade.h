@@ -336,6 +336,14 @@ PTK_HD float camera_entry_shift(const SceneView& sc, const CameraView& cam)
   return dist - fmaxf(0.5f * diag, dist * (1.0f / 1024.0f));
 }
 
+// Where a path keeps the two vectors that only wait while its shadow ray is traced (the light's contribution and the
+// direction of the segment that follows): in the path state itself, or wherever the caller's policy puts them (the
+// render kernel parks them in LDS, which takes six registers out of the traversal loops).
+struct ParkInState {
+  PTK_HD void store(PathState& ps, v3 pending, v3 next_d) const { ps.pending = pending; ps.next_d = next_d; }
+  PTK_HD void load(const PathState& ps, v3& pending, v3& next_d) const { pending = ps.pending; next_d = ps.next_d; }
+};
+
 struct SumAccum {  // accumulator of a one-pixel tile
   v3 sum;
   PTK_HD void add(uint32_t, v3 L) { sum += L; }
@@ -406,7 +414,7 @@ PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, con
 template <class M, class Mem>
 PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, const M& m, const Surface& s,
                       v3 albedo, v3 incoming, v3 scale, v3& to_light_out, float& distance_out, float& t_stop_out,
-                      uint32_t& light_id_out, const Mem& mem)
+                      uint32_t& light_id_out, v3& pending_out, const Mem& mem)
 {
   if (sc.n_lights == 0) return false;
   int idx = (int)(rnd(ps.g) * (float)sc.n_lights);  // Scene::random_light, src/scene.cpp:64-71
@@ -455,7 +463,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
   } else {
     f = bsdf_eval(fl, m, albedo, V3(0.0f, 1.0f, 0.0f), V3(0.0f, 1.0f, 0.0f));
   }
-  ps.pending = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
+  pending_out = scale * ld3(light.emission) * f * (weight * (float)sc.n_lights);
   light_id_out = light.id;
   to_light_out = to_light;
   distance_out = distance;
@@ -467,9 +475,9 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
 }
 
 // A path segment's query has finished: shade the vertex it found.  Returns true when the path ends here.
-template <class Stack, class Mem = GlobalMem>
+template <class Stack, class Mem = GlobalMem, class Park = ParkInState>
 PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
-                       Counters& cnt, const Mem& mem = Mem())
+                       Counters& cnt, const Mem& mem = Mem(), const Park& park = Park())
 {
   const v3 o = ps.tr.o, d = ps.tr.d;
 #ifdef PTK_BURN_SHADE
@@ -507,13 +515,13 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   ps.beta = scale * bsdf_eval(fl, m, albedo, wo, wi);
   ps.prev_specular = specular;
   ps.tr.o = s.point;
-  v3 to_light;
+  v3 to_light, pending;
   float distance, t_stop;
   uint32_t light_id;
   if (fl.direct_light_sampling && !specular &&
-      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id, mem)) {
+      nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id, pending, mem)) {
     ps.shadow = true;
-    ps.next_d = next_d;
+    park.store(ps, pending, next_d);
     cnt.queries++;
     // the light is at `distance`: nothing farther can be the closest hit that counts
     // the light the ray must reach stays in the query (Traversal::target) until the result is used
@@ -525,13 +533,15 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
 
 // A shadow ray's query has finished: add the light's contribution if the light is what it reached,
 // then start the path's next segment.  Returns true when the path ends here.
-template <class Stack>
+template <class Stack, class Park = ParkInState>
 PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
-                                Counters& cnt)
+                                Counters& cnt, const Park& park = Park())
 {
-  if (ps.tr.hit.id == ps.tr.target) ps.L += ps.pending;  // src/renderer.cpp:146
+  v3 pending, next_d;
+  park.load(ps, pending, next_d);
+  if (ps.tr.hit.id == ps.tr.target) ps.L += pending;  // src/renderer.cpp:146
   // the shadow ray left the vertex the next segment leaves: same origin, same primitive to skip
-  return path_next_segment(ps, st, sc, pp, fl, ps.next_d, ps.tr.skip_id, cnt);
+  return path_next_segment(ps, st, sc, pp, fl, next_d, ps.tr.skip_id, cnt);
 }
 
 // The lane's query has finished: use its result and set up the next query of the path.  Returns

@@ -14,19 +14,24 @@ and the 1.3 M-triangle scene (the two scenes the metric is quoted on) are measur
 reported under "extra", each with its own roofline and CPU baseline.
 
 N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (children under
-torch.distributed.run, before this process touches a GPU); under torch.distributed.run it is a rank.  Every GPU
-renders `spp` samples of the frame with interleaved global sample indices (weak scaling: the frame gets
-N x spp samples; --split tile shares one frame's rows instead) and the accumulation buffers are merged onto
-rank 0 with one RCCL collective per frame, inside the timed region.
+torch.distributed.run, before this process touches a GPU); under torch.distributed.run it is a rank.  The accumulation
+buffers are merged onto rank 0 with ONE RCCL collective per frame, inside the timed region; its bytes and time are also
+reported by themselves ("merge").  With the default `--workload all` the N > 1 run times the three multi-GPU
+configurations the metric names, each sharing ONE fixed frame (strong scaling: the frame is the same whatever N):
+  top level  `bmw`    1.31 M triangles, 3840 x 2160, 1024 spp, interleaved 16-row bands per GPU + a gather
+  extra      `glass`  dielectric scene, 500 x 500, 8 bounces, 8192 spp shared by sample index + a sum-reduce
+  extra      `envmap` textured scene + environment map + depth of field, 1920 x 1080, 1024 spp shared by sample index
+A named workload (`--workload bunny --gpus N`) is shared by --split (default spp) under --scaling (default weak for
+spp: every GPU renders `spp` samples, the frame gets N x spp; strong: the frame's `spp` samples are shared).
 
-Roofline: nothing here is a dense contraction and the scenes are cache resident, so the bound that applies
-is the fp32 vector rate: algorithmic flops per ray (21 per box test, 60 per primitive test, 250 per shaded
-segment; tests per ray counted by an instrumented launch on the same scene) x rays per launch / the kernel's
-launch time from HIP events on its own stream, against 157.3 TFLOP/s.  The same accounting in bytes (32 per
-box test, 36 per primitive test, 48 per ray) is reported as "algorithmic_gbs": it exceeds the HBM peak because
-those bytes come from L1 / L2, which is why HBM is not the bound; "traffic" is the HBM-side byte count per
-launch measured with the hardware counters (profiles/traffic.json), "hbm_frac" that traffic over the launch
-time against 8 TB/s.  "frac" is the larger of the two fractions.
+Roofline: nothing here is a dense contraction.  Two fractions are computed and the larger is reported as "frac":
+the fp32 vector rate (algorithmic flops per ray: 21 per box test, 60 per primitive test, 250 per shaded segment;
+tests per ray counted by an instrumented launch on the same scene; x rays per launch / the kernel's launch time from
+HIP events on its own stream, against 157.3 TFLOP/s), and the measured HBM-side traffic per launch from the hardware
+counters (profiles/traffic.json) over the launch time against 8 TB/s ("hbm_frac").  The same accounting in bytes
+(32 per box test, 36 per primitive test, 48 per ray) is "algorithmic_gbs", and "bytes_frac_survey" is that figure over
+the HBM peak: it exceeds 1 because those bytes are what the lanes ask the CACHES for (L1 / L2 / Infinity Cache serve
+most of them), so it measures cache-level demand, not HBM use, and is not the reported fraction.
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,7 +111,13 @@ def cpu_baseline(sd, spp_max, bounces, budget_s):
             "box_tests_per_ray": c["box_tests"] / max(1, c["queries"]),
             "single_thread": {"segments_per_s": c1["segments"] / dt1, "rays_per_s": c1["queries"] / dt1,
                               "sample": f"rows {y1}..{y1 + 8}, {spp1} spp, {dt1:.2f} s",
-                              "reference_single_thread_segments_per_s_cornell": 0.908e6}}
+                              "reference_single_thread_segments_per_s_cornell": 0.908e6,
+                              "explanation": "this restatement runs faster per thread than the reference binary (0.908 M segments/s on the Cornell box, "
+                                             "8-core Xeon VM of the survey) because it has no process-global state: the reference draws every random "
+                                             "number from one shared std::mt19937 (src/util.h:72-78, two engine draws per double) and bumps two global "
+                                             "atomics per primitive test and per segment (src/geometry.cpp:162, src/renderer.cpp:63); here the generator "
+                                             "is a counter hash and the counters are per thread.  The algorithm (tree, tests per ray, estimator) is the "
+                                             "reference's; the host CPU also differs from the survey container's"}}
 
 
 def traffic_entry(key):
@@ -119,10 +130,17 @@ def traffic_entry(key):
         return None
 
 
-def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
-    """Times `args.steps` frames of one workload; returns the result dictionary (rank 0) or None."""
+def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu, split, scaling):
+    """Times `args.steps` frames of one workload; returns the result dictionary (rank 0) or None.
+    split: how the ranks share a frame; scaling "strong": the frame has `spp` samples whatever the number of ranks,
+    "weak" (sample split only): every rank renders `spp` samples."""
     from pathtracer_amd import parallel
     width, height, spp, bounces = args.sizes[name]
+    if world > 1 and split == "spp" and scaling == "strong":
+        mine = (spp - rank + world - 1) // world  # samples rank, rank + world, ... below spp
+    else:
+        mine = spp
+    frame_spp = spp * world if (world > 1 and split == "spp" and scaling == "weak") else spp
     sd = build_scene(name, width, height)
     ctx.upload_scene(sd, args.builder)
     ctx.set_camera(sd.camera)
@@ -130,8 +148,9 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
     accum = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     ctx.bind_accum(accum.data_ptr())
-    plan = parallel.frame_plan(args.split, rank, world, spp, height, batch=args.batch)
-    merge = parallel.FrameMerge(args.split, rank, world, accum)
+    plan = parallel.frame_plan(split, rank, world, mine, height, batch=args.batch)
+    merge = parallel.FrameMerge(split, rank, world, accum)
+    merge_s = [0.0]
 
     def frame(step):
         accum.zero_()
@@ -141,10 +160,18 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
                        sample_stride=c.sample_stride, row_begin=c.row_begin, row_end=c.row_end,
                        band_rows=c.band_rows, band_first=c.band_first, band_stride=c.band_stride)
         ctx.synchronize()
+        if world > 1:
+            dist.barrier()  # the merge is timed from the moment the slowest rank has rendered
+            torch.cuda.synchronize()
+            t_merge = time.perf_counter()
         merge.run()  # RCCL over xGMI: the frame's one exchange step
+        if world > 1:
+            torch.cuda.synchronize()
+            merge_s[0] += time.perf_counter() - t_merge
 
     for w in range(args.warmup):
         frame(-1 - w)
+    merge_s[0] = 0.0
     ctx.reset_stats()
     if world > 1:
         dist.barrier()
@@ -170,7 +197,7 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
     ctx.reset_stats()
     accum.zero_()
     torch.cuda.synchronize()
-    ctx.render(max(1, min(args.stats_spp, spp)), bounces, seed=7, collect_stats=True)
+    ctx.render(max(1, min(args.stats_spp, spp)), bounces, seed=7, collect_stats=True, row_end=min(height, 1024))
     si = ctx.stats()
     ctx.bind_accum(None)
     box_per_ray = si["box_tests"] / max(1, si["queries"])
@@ -203,28 +230,47 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu):
                 "prim_tests_per_ray": prim_per_ray, "box_tests_counted": box_counted, "prim_tests_counted": prim_counted,
                 "rays_per_launch": rays_per_launch,
                 "algorithmic_gbs": algorithmic_gbs, "algorithmic_bytes_per_launch": rays_per_launch * bytes_per_ray,
-                "note": "scene is cache resident: algorithmic bytes are served by L1/L2, HBM traffic is a few percent of "
-                        "its peak, so the fp32 vector rate is the bound reported; 'units' holds the hardware counters of "
-                        "the same launch from profiles/ (busy fractions of the vector ALU, the L1's address and data units)"}
+                "bytes_frac_survey": algorithmic_gbs / PEAK_HBM_GBS,
+                "bytes_frac_survey_note": "algorithmic bytes (32 per box test, 36 per primitive test, 48 per ray) over the HBM peak: "
+                                          "what the lanes ask the caches for, most of it served by L1 / L2 / Infinity Cache; above 1 by "
+                                          "construction on these scenes and NOT the reported fraction",
+                "note": "scene is cache resident: HBM-side traffic is a few percent of the HBM peak, so the fp32 vector rate is the "
+                        "bound reported; 'units' holds the hardware counters of the same launch from profiles/ (busy fractions of "
+                        "the vector ALU, the L1's address and data units)"}
     if tr:
         roofline["units"] = {k: tr.get(k) for k in ("l1_hit_rate", "l2_hit_rate", "valu_lane_utilisation", "valu_fast_share",
                                                     "valu_pipe_occupancy_lower", "valu_pipe_occupancy_upper", "ta_busy", "td_busy",
                                                     "l1_latency_cycles", "wait_fraction") if tr.get(k) is not None}
+    if traffic is None:
+        roofline["note"] = ("no hardware-counter pass is committed for this configuration (profiles/traffic.json): only the fp32 "
+                            "vector-rate fraction is known")
     if hbm_frac is not None and hbm_frac > valu_frac:
-        roofline.update({"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac})
+        roofline.update({"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac,
+                         "note": "the scene (%.0f MB of nodes, primitive and shading records) does not fit the 4 MB L2 of an XCD: the "
+                                 "measured bytes that leave the L2 per launch (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json: an upper "
+                                 "bound on HBM bytes, the 256 MB Infinity Cache serves part of them) over the launch time are the larger "
+                                 "fraction; 'valu_frac' is the fp32 vector-rate fraction of the same launch"
+                                 % ((info["node_bytes"] + info["prim_bytes"] + info["shading_bytes"]) / 1e6),
+                         "valu_frac": valu_frac})
     out = {
         "value": queries / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / args.steps * 1e3,
-        "config": {"workload": f"{name}: {WORKLOADS[name]}; {width}x{height}, {spp} spp per GPU, {bounces} bounces",
+        "config": {"workload": f"{name}: {WORKLOADS[name]}; {width}x{height}, {frame_spp} spp per frame"
+                               + (f" ({mine} on this GPU)" if world > 1 and split == "spp" else "") + f", {bounces} bounces",
                    "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"],
                    "bvh_builder": "device" if info["builder"] else "host",
                    "scene_upload_ms": round(info["upload_ms"], 2), "device_build_ms": round(info["device_build_ms"], 3),
-                   "split": (f"{args.split} split, {merge.describe()}" if world > 1 else "none"),
+                   "split": (f"{split} split, {merge.describe()}" if world > 1 else "none"),
                    "launches_per_frame": st["launches"] // max(1, args.steps)},
         "ms_per_frame": elapsed / args.steps * 1e3,
         "segments_per_s": segments / elapsed, "paths_per_s": camera_rays / elapsed,
         "rays_per_segment": queries / max(1.0, segments),
         "roofline": roofline,
     }
+    if world > 1:
+        out["scaling"] = scaling
+        out["merge"] = {"bytes_per_rank": merge.bytes_per_rank(), "ms_per_frame": merge_s[0] / args.steps * 1e3,
+                        "collective": "gather" if split == "tile" else "reduce",
+                        "note": "inside the timed region; measured between a barrier after the slowest rank's render and the end of the collective"}
     if cpu:
         out["cpu_baseline"] = cpu
     return out
@@ -257,19 +303,36 @@ def main(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         print(f"[bench] rank {rank}/{world} on {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank})", file=sys.stderr, flush=True)
 
-    names = ["bunny", "cornell", "bmw"] if args.workload == "all" else [args.workload]
-    if world > 1 and args.workload == "all":
-        names = ["bunny"]  # the scaling runs time the headline workload only
+    # (workload, split, scaling) per timed configuration
+    if args.workload != "all":
+        split = args.split or "spp"
+        runs = [(args.workload, split, args.scaling or ("weak" if split == "spp" else "strong"))]
+    elif world > 1:
+        # the multi-GPU configurations the metric names, each one fixed frame shared by the GPUs
+        args.sizes["bmw"] = (args.width or 3840, args.height or 2160, args.spp or 1024, args.sizes["bmw"][3])
+        args.sizes["glass"] = (args.sizes["glass"][0], args.sizes["glass"][1], args.spp or 8192, args.sizes["glass"][3])
+        runs = [("bmw", "tile", "strong"), ("glass", "spp", "strong"), ("envmap", "spp", "strong")]
+    else:
+        runs = [("bunny", "spp", "weak"), ("cornell", "spp", "weak"), ("bmw", "spp", "weak")]
+    names = [r[0] for r in runs]
+    if world > 1:
+        # every rank builds the same tree on the host: share the cores instead of 16 builder threads per rank
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 16
+        os.environ.setdefault("PTK_BUILD_THREADS", str(max(2, min(16, cores // world))))
     ctx = native.Context(local_rank)
     results = {}
-    for name in names:
-        results[name] = run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu=(world == 1 and not args.no_cpu))
+    for name, split, scaling in runs:
+        results[name] = run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu=(world == 1 and not args.no_cpu),
+                                     split=split, scaling=scaling)
     if rank == 0:
         head = results[names[0]]
         out = {"metric": "Mrays/s", "value": head["value"], "unit": "Mrays/s",
                "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": head["ms_per_step"], "higher_is_better": True,
-               "scaling": "weak" if args.split == "spp" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+               "scaling": runs[0][2], "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
         out.update({k: v for k, v in head.items() if k not in ("value", "unit", "ms_per_step")})
         if len(names) > 1:
             out["extra"] = {n: results[n] for n in names[1:]}
@@ -308,8 +371,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="samples per launch (0 = the whole frame in one launch)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--stats-spp", type=int, default=4, help="samples per pixel of the instrumented (test-counting) pass")
-    ap.add_argument("--split", default="spp", choices=["spp", "tile"],
-                    help="how N > 1 GPUs share a frame: interleaved sample indices or interleaved row bands")
+    ap.add_argument("--split", default=None, choices=["spp", "tile"],
+                    help="how N > 1 GPUs share a frame of a named workload: interleaved sample indices (default) or interleaved row bands")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="named workload, N > 1, sample split: weak = every GPU renders --spp samples (default), strong = they share --spp")
     ap.add_argument("--builder", default=None, choices=["host", "device"],
                     help="tree builder (default: host surface-area-heuristic build; device: linear BVH built on the GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

@@ -272,6 +272,10 @@ int ptk_group_reset_accum(ptk_group* group);
  * with the band split leave row_begin, row_end and band_* zero. */
 int ptk_group_render(ptk_group* group, const ptk_render_params* params, int32_t split);
 int ptk_group_synchronize(ptk_group* group);
+/* print_stats (src/geometry.cpp:273-278) reports whole-run totals: the counters of all devices added up (kernel
+ * times: the slowest device's, since the devices work side by side).  Blocks. */
+int ptk_group_get_stats(ptk_group* group, ptk_stats* out);
+int ptk_group_reset_stats(ptk_group* group);
 /* ptk_read_accum / ptk_read_display_u8 of the whole frame: reduce onto device 0, then read.  Block. */
 int ptk_group_read_accum(ptk_group* group, float* rgb, int32_t* total_samples);
 int ptk_group_read_display_u8(ptk_group* group, uint8_t* rgb8, int32_t* total_samples);

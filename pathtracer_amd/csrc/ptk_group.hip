@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -182,6 +183,9 @@ int ptk_group_upload_scene(ptk_group* g, const ptk_scene_desc* scene, int32_t bu
     if (rc != PTK_OK) gfail(g, rc, "ptk_group_upload_scene (device " + std::to_string(g->device[i]) + "): " + ptk_last_error(g->ctx[i]));
   }
   ptk::ctx_release_host_copy(g->ctx[0]);
+  // all devices or none: a group with the scene on some of its devices only would render part of a frame
+  if (rc != PTK_OK)
+    for (ptk_ctx* c : g->ctx) ptk::ctx_drop_scene(c);
   return rc;
 }
 
@@ -235,6 +239,34 @@ int ptk_group_synchronize(ptk_group* g)
   return for_each_context(g, "ptk_group_synchronize", [&](ptk_ctx* c, int) { return ptk_synchronize(c); });
 }
 
+int ptk_group_get_stats(ptk_group* g, ptk_stats* out)
+{
+  if (!g) return PTK_ERR_INVALID;
+  if (!out) return gfail(g, PTK_ERR_INVALID, "ptk_group_get_stats: out is NULL");
+  ptk_stats sum;
+  std::memset(&sum, 0, sizeof sum);
+  int rc = for_each_context(g, "ptk_group_get_stats", [&](ptk_ctx* c, int) {
+    ptk_stats st;
+    int r = ptk_get_stats(c, &st);
+    if (r != PTK_OK) return r;
+    sum.camera_rays += st.camera_rays; sum.segments += st.segments; sum.queries += st.queries;
+    sum.box_tests += st.box_tests; sum.prim_tests += st.prim_tests;
+    sum.launches += st.launches;
+    // the devices work side by side: the slowest one's kernel time is the group's
+    sum.kernel_ms_last = std::max(sum.kernel_ms_last, st.kernel_ms_last);
+    sum.kernel_ms_total = std::max(sum.kernel_ms_total, st.kernel_ms_total);
+    return (int)PTK_OK;
+  });
+  if (rc == PTK_OK) *out = sum;
+  return rc;
+}
+
+int ptk_group_reset_stats(ptk_group* g)
+{
+  if (!g) return PTK_ERR_INVALID;
+  return for_each_context(g, "ptk_group_reset_stats", [&](ptk_ctx* c, int) { return ptk_reset_stats(c); });
+}
+
 }  // extern "C"
 
 // Sum of all contexts' buffers in g->d_merged (device 0).
@@ -262,7 +294,11 @@ static int merge_frame(ptk_group* g)
       nr = r.reduce(ptk::ctx_accum(g->ctx[i]), g->d_merged, pixels * 4, ncclFloat, ncclSum, 0, g->comm[i], (hipStream_t)ptk_stream(g->ctx[i]));
     ncclResult_t ne = r.group_end();
     if (nr == ncclSuccess) nr = ne;
-    if (nr != ncclSuccess) return gfail(g, PTK_ERR_HIP, std::string("ptk_group: ncclReduce: ") + r.error_string(nr));
+    if (nr != ncclSuccess) {
+      // whatever part of the collective was queued must have drained before the caller may touch the buffers again
+      for (ptk_ctx* c : g->ctx) (void)ptk_synchronize(c);
+      return gfail(g, PTK_ERR_HIP, std::string("ptk_group: ncclReduce: ") + r.error_string(nr));
+    }
     return ptk_group_synchronize(g);
   }
   hipStream_t s0 = (hipStream_t)ptk_stream(g->ctx[0]);

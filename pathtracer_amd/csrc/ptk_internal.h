@@ -17,5 +17,6 @@ void ctx_set_error(ptk_ctx* ctx, const std::string& msg);
 int ctx_upload_keep_host(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder);
 int ctx_upload_like(ptk_ctx* to, ptk_ctx* from);
 void ctx_release_host_copy(ptk_ctx* ctx);
+void ctx_drop_scene(ptk_ctx* ctx);                // frees the context's scene: later renders fail cleanly with "upload a scene first"
 
 }  // namespace ptk

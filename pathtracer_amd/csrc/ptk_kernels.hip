@@ -822,6 +822,7 @@ struct ptk_ctx {
   unsigned long long* d_counters = nullptr;
   unsigned int* d_unit_queue = nullptr;  // the render kernel's work-unit counters, one cache line per XCD
   int intersect_resident[2] = {0, 0};  // waves of the ray-batch kernel that fit the GPU at once: shallow form, deep form
+  int render_resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... and of the render kernel, per form (resident_workgroups)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
   double ms_last = 0.0, ms_total = 0.0;
   uint64_t launches = 0;
@@ -900,9 +901,9 @@ static int upload(ptk_ctx* ctx, void** dst, const std::vector<T>& src)
 // ends with most CUs idle while the slowest tiles finish; splitting every tile's samples over
 // several workgroups shortens that tail.  Each chunk keeps at least kMinChunkSamples samples so
 // that a lane still has work to refill with when its neighbours' paths end.
-static int pick_chunks(int n_tiles, int samples, int waves_per_simd)
+static int pick_chunks(int n_tiles, int samples, int64_t resident_waves)
 {
-  const int64_t kResidentWaves = 256 * 4 * waves_per_simd;
+  const int64_t kResidentWaves = resident_waves;
   constexpr int64_t kRounds = PTK_CHUNK_ROUNDS;
   constexpr int kMinChunkSamples = PTK_CHUNK_MIN_SAMPLES;
   int64_t waves = (int64_t)n_tiles;
@@ -937,6 +938,48 @@ static void release_host_copy(ptk_ctx* ctx)
   std::vector<float>().swap(ctx->host.prim_boxes);
   if (ctx->builder == PTK_BUILDER_DEVICE_LBVH) std::vector<PrimRec>().swap(ctx->host.prims);  // id order: not the device's order
   ctx->have_scene_host = false;
+}
+
+using RenderKernel = void (*)(SceneView, const DeviceConsts*, RenderArgs, f4*, f4*, unsigned long long*, unsigned int*);
+static RenderKernel render_kernel_for(int form, bool stats)
+{
+  switch (form) {
+    case kFormSpillTables: return stats ? render_kernel<true, kFormSpillTables> : render_kernel<false, kFormSpillTables>;
+    case kFormShallowTables: return stats ? render_kernel<true, kFormShallowTables> : render_kernel<false, kFormShallowTables>;
+    case kFormSpill: return stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>;
+    case kFormDeep: return stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>;
+    case kFormTiny: return stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>;
+    default: return stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>;
+  }
+}
+// the form of the render kernel that the scene in use runs (see the forms' description at the kernel)
+static int render_form(const ptk_ctx* ctx)
+{
+  return ctx->lds_tables ? (ctx->tables_spill ? kFormSpillTables : kFormShallowTables)
+         : ctx->spill_stack ? kFormSpill : ctx->deep_tree ? kFormDeep : ctx->tiny_scene ? kFormTiny : kFormShallow;
+}
+
+// One-wave workgroups of `kernel` that the device holds at once: what the occupancy query says, corrected for the
+// 1280-byte granules LDS is handed out in (which the query does not know), times the device's compute units,
+// rounded down to a multiple of 8 (the render kernel's persistent launch gives every XCD the same number).
+// Asked once per context and kernel form, when a scene that runs the form is uploaded (ptk_render_static must not be the first to ask).
+static int resident_workgroups(ptk_ctx* ctx, RenderKernel kernel, int& cached)
+{
+  if (cached > 0) return cached;
+  int per_cu = 0, cus = 0, lds_per_cu = 0;
+  hipFuncAttributes fa;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess ||
+      hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) != hipSuccess ||
+      hipDeviceGetAttribute(&lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, ctx->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return cached = 256 * 4 * PTK_MIN_WAVES_SHALLOW;  // the MI355X figure
+  }
+  constexpr int kLdsGranule = 1280;
+  const int lds = ((int)fa.sharedSizeBytes + kLdsGranule - 1) / kLdsGranule * kLdsGranule;
+  if (lds > 0 && lds_per_cu > 0) per_cu = std::min(per_cu, lds_per_cu / lds);
+  const int n = std::max(1, per_cu) * std::max(1, cus);
+  return cached = std::max(8, n / 8 * 8);
 }
 
 // Second half of an upload: ctx->host holds the flattened scene (build_host_scene); build the tree on the device
@@ -1009,6 +1052,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
   if (!keep_host) release_host_copy(ctx);  // the largest host copies are no longer needed
   ctx->upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->have_scene = true;
+  (void)resident_workgroups(ctx, render_kernel_for(render_form(ctx), false), ctx->render_resident[render_form(ctx)]);
   return sync_consts(ctx);
 }
 
@@ -1107,8 +1151,7 @@ int ptk_scene_info_get(const ptk_ctx* ctx, ptk_scene_info* out)
   out->n_nodes = ctx->n_nodes;
   out->max_depth = h.max_depth;
   out->max_leaf_size = h.max_leaf;
-  out->traversal_kind = ctx->lds_tables ? (ctx->tables_spill ? kFormSpillTables : kFormShallowTables)
-                        : ctx->spill_stack ? kFormSpill : ctx->deep_tree ? kFormDeep : ctx->tiny_scene ? kFormTiny : kFormShallow;
+  out->traversal_kind = render_form(ctx);
   out->node_bytes = (uint64_t)ctx->n_nodes * sizeof(NodePair);
   out->prim_bytes = (uint64_t)std::max(h.n_prims, 1) * sizeof(PrimRec);
   out->shading_bytes = h.shade.size() * sizeof(ShadeRec) + h.materials.size() * sizeof(MaterialRec) + h.lights.size() * sizeof(LightRec);
@@ -1213,8 +1256,11 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   int tiles_y = (launch_rows + kTile - 1) / kTile;
   ra.rows = tiles_y * kTile;
   ra.n_tiles = ra.tiles_x * tiles_y;
-  ra.chunks = pick_chunks(ra.n_tiles, p->samples, ctx->deep_tree && !ctx->spill_stack ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
   PTK_HIP(hipSetDevice(ctx->device));
+  const int form = render_form(ctx);
+  RenderKernel kernel = render_kernel_for(form, p->collect_stats != 0);
+  const int64_t resident = resident_workgroups(ctx, kernel, ctx->render_resident[form]);  // one wave each
+  ra.chunks = pick_chunks(ra.n_tiles, p->samples, resident);
   size_t band_pixels = (size_t)ra.rows * (size_t)ctx->cam.width;
   f4* partial = ctx->d_partial;
   if (static_scratch) {
@@ -1246,17 +1292,10 @@ static int render_common(ptk_ctx* ctx, const ptk_render_params* p, bool static_s
   if (rc) return rc;
   // More units than fit the GPU at once: as many workgroups as fit, which draw the units from per-XCD counters.
   const int64_t n_units = (int64_t)ra.n_tiles * ra.chunks;
-  const int64_t resident = 256 * 4 * (int64_t)(ctx->deep_tree && !ctx->spill_stack ? PTK_MIN_WAVES : PTK_MIN_WAVES_SHALLOW);
   // (+0.2-0.4 % on the mesh scenes; the Cornell box's whole-scene-in-LDS form loses as much and keeps one workgroup per unit)
   ra.persistent = n_units > resident && !ctx->tiny_scene && getenv("PTK_NO_PERSISTENT") == nullptr ? 1 : 0;
   if (ra.persistent) PTK_HIP(hipMemsetAsync(ctx->d_unit_queue, 0, kUnitQueueBytes, ctx->stream));
   dim3 grid((unsigned)(ra.persistent ? resident : n_units)), block(kBlock);
-  auto kernel = ctx->lds_tables   ? (ctx->tables_spill ? (p->collect_stats ? render_kernel<true, kFormSpillTables> : render_kernel<false, kFormSpillTables>)
-                                                        : (p->collect_stats ? render_kernel<true, kFormShallowTables> : render_kernel<false, kFormShallowTables>))
-                : ctx->spill_stack  ? (p->collect_stats ? render_kernel<true, kFormSpill> : render_kernel<false, kFormSpill>)
-                : ctx->deep_tree    ? (p->collect_stats ? render_kernel<true, kFormDeep> : render_kernel<false, kFormDeep>)
-                : ctx->tiny_scene ? (p->collect_stats ? render_kernel<true, kFormTiny> : render_kernel<false, kFormTiny>)
-                                  : (p->collect_stats ? render_kernel<true, kFormShallow> : render_kernel<false, kFormShallow>);
   hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ctx->view, ctx->d_consts, ra, ctx->d_accum, partial, ctx->d_counters,
                      ctx->d_unit_queue);
   PTK_HIP(hipGetLastError());
@@ -1461,6 +1500,12 @@ size_t ctx_accum_pixels(const ptk_ctx* ctx) { return ctx->have_camera ? ctx->acc
 void ctx_set_error(ptk_ctx* ctx, const std::string& msg) { ctx->err = msg; }
 int ctx_upload_keep_host(ptk_ctx* ctx, const ptk_scene_desc* scene, int32_t builder) { return upload_scene_impl(ctx, scene, builder, true); }
 void ctx_release_host_copy(ptk_ctx* ctx) { release_host_copy(ctx); }
+void ctx_drop_scene(ptk_ctx* ctx)
+{
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_scene(ctx);
+}
 
 // Gives `to` the scene that `from` holds on the host side (the flattened records and, for a host-built tree,
 // the tree) and uploads it to `to`'s GPU: the tree is built once for all GPUs of a group.

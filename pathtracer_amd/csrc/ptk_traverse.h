@@ -436,7 +436,8 @@ PTK_HD bool closest_hit(const SceneView& sc, v3 o, v3 d, float tmax, uint32_t sk
 {
   Traversal tr;
   const float shift = scene_entry_shift(sc, o, d);
-  trav_begin(tr, st, sc, o + d * shift, d, tmax, skip_id);
+  // distances are measured from the moved origin until the shift is added back below: a finite tmax moves with it
+  trav_begin(tr, st, sc, o + d * shift, d, tmax < kTMax ? tmax - shift : tmax, skip_id);
   while (!trav_done(tr)) {
     if (trav_at_inner(tr)) trav_inner<Stack, STATS>(tr, st, sc, cnt);
     else trav_leaf<Stack, STATS>(tr, st, sc, cnt);

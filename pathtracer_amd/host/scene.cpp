@@ -311,9 +311,9 @@ std::optional<Intersection> Scene::find_intersection(const Ray& ray) const
 
 void Scene::print_stats() const
 {
-  if (!m_ctx) return;
-  ptk_stats st;
-  if (ptk_get_stats(m_ctx, &st) != PTK_OK) return;
+  if (!m_group) return;
+  ptk_stats st;  // whole-run totals over every device of the group, as the reference's global counters are
+  if (ptk_group_get_stats(m_group, &st) != PTK_OK) return;
   std::cout << "Path Segments: " << st.segments << std::endl;
   std::cout << "Intersection Queries: " << st.queries << std::endl;
   if (st.prim_tests) std::cout << "Intersection Test Count: " << st.prim_tests << std::endl;

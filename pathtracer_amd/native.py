@@ -92,7 +92,7 @@ EXPORTS = ["ptk_create", "ptk_destroy", "ptk_last_error", "ptk_upload_scene", "p
            "ptk_intersect_batch", "ptk_intersect_batch_device", "ptk_get_stats", "ptk_reset_stats", "ptk_stream",
            "ptk_group_create", "ptk_group_destroy", "ptk_group_last_error", "ptk_group_size", "ptk_group_context",
            "ptk_group_upload_scene", "ptk_group_set_camera", "ptk_group_set_flags", "ptk_group_reset_accum", "ptk_group_render",
-           "ptk_group_synchronize", "ptk_group_read_accum", "ptk_group_read_display_u8"]
+           "ptk_group_synchronize", "ptk_group_get_stats", "ptk_group_reset_stats", "ptk_group_read_accum", "ptk_group_read_display_u8"]
 SPLITS = {"spp": 0, "tile": 1}  # PTK_SPLIT_SAMPLES, PTK_SPLIT_BANDS
 
 
@@ -214,6 +214,8 @@ def load_library():
     L.ptk_group_reset_accum.argtypes = [vp]
     L.ptk_group_render.argtypes = [vp, C.POINTER(PtkRenderParams), C.c_int32]
     L.ptk_group_synchronize.argtypes = [vp]
+    L.ptk_group_get_stats.argtypes = [vp, C.POINTER(PtkStats)]
+    L.ptk_group_reset_stats.argtypes = [vp]
     L.ptk_group_read_accum.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.ptk_group_read_display_u8.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     _lib = L
@@ -365,6 +367,15 @@ class Group:
         if rc != 0:
             raise PtkError(f"ptk_get_stats failed ({rc})")
         return s.as_dict()
+
+    def stats(self):
+        """ptk_group_get_stats: the counters of all devices added up."""
+        s = PtkStats()
+        self._check(self._L.ptk_group_get_stats(self.h, C.byref(s)), "ptk_group_get_stats")
+        return s.as_dict()
+
+    def reset_stats(self):
+        self._check(self._L.ptk_group_reset_stats(self.h), "ptk_group_reset_stats")
 
     def upload_scene(self, sd, builder="host"):
         desc, keep = make_scene_desc(sd)

@@ -28,7 +28,9 @@ def _single(sd, calls, bounces, seed, builder="host"):
         ctx.set_camera(sd.camera)
         for first, n in calls:
             ctx.render(n, bounces, seed=seed, sample_first=first)
-        return ctx.read_accum()
+        img, total = ctx.read_accum()
+        _single.stats = ctx.stats()
+        return img, total
     finally:
         ctx.close()
 
@@ -52,6 +54,10 @@ def test_group_frame_equals_the_single_gpu_frame(devices, split):
         assert total == want_total == 27
         assert np.allclose(got, want, rtol=3e-5, atol=1e-6)
         assert not np.array_equal(got, first)
+        # the group's counters are the whole run's, equal to what one device counts for the same paths
+        whole = g.stats()
+        for key in ("camera_rays", "segments", "queries"):
+            assert whole[key] == _single.stats[key], (key, whole[key], _single.stats[key])
         shares = [g.context_stats(i)["camera_rays"] for i in range(len(devices))]
         assert sum(shares) == 27 * sd.camera.width * sd.camera.height
         assert min(shares) > 0.2 * max(shares)  # every device took a real share

@@ -203,10 +203,15 @@ def test_pt_with_environment_map_file_and_textured_sphere(host, tmp_path, device
     tex = sd.add_texture(globe)
     sd.add_sphere((0.5, 1.2, 1.5), 1.2, sd.add_material(scenes.Material(albedo=(1.0, 1.0, 1.0), texture=tex)))
     sd.background_texture = sd.add_texture(decoded)
-    ref, _ = orc.OracleScene(sd).render(24, 3, seed=9)
+    ref, counters = orc.OracleScene(sd).render(24, 3, seed=9)
     d = np.abs(got - orc.tonemap_u8(ref).astype(int))
     print(devices, split, "mean abs diff", d.mean())
     assert d.mean() < 2.0
+    # print_stats (src/geometry.cpp:273-278) reports whole-run totals, however many devices shared the frame
+    import re
+    printed = {k: int(v) for k, v in re.findall(r"(Path Segments|Intersection Queries): (\d+)", r.stdout)}
+    assert abs(printed["Path Segments"] - counters["segments"]) <= 0.005 * counters["segments"], (printed, counters)
+    assert abs(printed["Intersection Queries"] - counters["queries"]) <= 0.005 * counters["queries"], (printed, counters)
 
 
 def test_tree_cache_round_trip(tmp_path, monkeypatch):

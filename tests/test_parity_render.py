@@ -261,3 +261,11 @@ def test_persistent_launch_renders_the_same_bits(gpu_ctx, monkeypatch):
     assert np.array_equal(first, again)
     assert np.array_equal(first, plain)
     assert cnt_first == cnt_plain
+    # the same with the test-counting form of the kernel (per-lane counts are folded into the wave's totals after every
+    # unit a persistent workgroup draws): same frame, and the same counts as one workgroup per unit
+    plain_counted, cnt_plain_counted = b.render(128, 3, seed=21, collect_stats=True)
+    monkeypatch.delenv("PTK_NO_PERSISTENT")
+    counted, cnt_counted = b.render(128, 3, seed=21, collect_stats=True)
+    assert cnt_counted == cnt_plain_counted and cnt_counted["box_tests"] > 0 and cnt_counted["prim_tests"] > 0
+    assert {k: cnt_counted[k] for k in ("camera_rays", "segments", "queries")} == {k: cnt_first[k] for k in ("camera_rays", "segments", "queries")}
+    assert np.array_equal(counted, plain_counted)

@@ -18,8 +18,8 @@ def _rows(gpu_ctx, sd, spp):
 
 @pytest.mark.gpu
 def test_gpu_frame_matches_the_published_spheres(gpu_ctx):
-    plain = _rows(gpu_ctx, pins._sphere_scene_data(), 256)
-    with_standin = _rows(gpu_ctx, pins._sphere_scene_data(standin=True), 256)
+    plain = _rows(gpu_ctx, pins._sphere_scene_data(), 64)
+    with_standin = _rows(gpu_ctx, pins._sphere_scene_data(standin=True), 64)
     stable = np.abs(plain - with_standin).max(axis=2) < 3.0
     for name, least in (("mirror", 45), ("glass", 110)):
         selected, agree, median = pins._block_report(plain, stable, name)

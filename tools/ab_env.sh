@@ -13,7 +13,7 @@ while read -r lib envs; do
   python3 - "$lib $envs" <<'PY' >> $O
 import json,sys
 d=json.loads(open('gpurun_out/_ab_one.json').read().strip().splitlines()[-1])
-print(sys.argv[1], "| Mrays/s", round(d["value"],1), "ms", round(d["ms_per_frame"],2))
+print(sys.argv[1], "|", d["config"]["workload"].split(":")[0], d["config"]["workload"].split(";")[-1].strip(), "| Mrays/s", round(d["value"],1), "ms", round(d["ms_per_frame"],2))
 PY
 done
 cat $O

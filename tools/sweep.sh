@@ -10,7 +10,7 @@ for lib in pathtracer_amd/variants/*.so; do
   python3 - "$lib" <<'PY' >> $OUT
 import json,sys
 d=json.loads(open('gpurun_out/_sweep_one.json').read().strip().splitlines()[-1])
-print(json.dumps({"lib":sys.argv[1].split('/')[-1],"Mrays/s":round(d["value"],1),"ms_per_frame":round(d["ms_per_frame"],2),"kernel_ms":round(d["roofline"]["kernel_ms_avg"],2)}))
+print(json.dumps({"lib":sys.argv[1].split('/')[-1],"workload":d["config"]["workload"].split(":")[0]+" "+d["config"]["workload"].split(";")[-1].strip(),"Mrays/s":round(d["value"],1),"ms_per_frame":round(d["ms_per_frame"],2),"kernel_ms":round(d["roofline"]["kernel_ms_avg"],2)}))
 PY
 done
 cat $OUT

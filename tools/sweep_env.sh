@@ -12,7 +12,7 @@ for v in $VALUES; do
   python3 - "$VAR=$v" <<'PY' >> $OUT
 import json,sys
 d=json.loads(open('gpurun_out/_sweep_one.json').read().strip().splitlines()[-1])
-print(json.dumps({"var":sys.argv[1],"Mrays/s":round(d["value"],1),"ms_per_frame":round(d["ms_per_frame"],2),"kernel_ms":round(d["roofline"]["kernel_ms_avg"],2)}))
+print(json.dumps({"var":sys.argv[1],"workload":d["config"]["workload"].split(":")[0]+" "+d["config"]["workload"].split(";")[-1].strip(),"Mrays/s":round(d["value"],1),"ms_per_frame":round(d["ms_per_frame"],2),"kernel_ms":round(d["roofline"]["kernel_ms_avg"],2)}))
 PY
 done
 cat $OUT

@@ -278,7 +278,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
 }
 
 struct CacheHeader {
-  char magic[8];  // "PTKBVH4\0"
+  char magic[8];  // "PTKBVH5\0"
   uint64_t key_a, key_b;
   int32_t n_prims, n_nodes, max_depth, max_leaf;
 };
@@ -328,7 +328,7 @@ bool cache_load(const std::string& path, CacheKey key, int32_t n_prims, std::vec
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   CacheHeader h;
-  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH4", 8) == 0 && h.key_a == key.a &&
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH5", 8) == 0 && h.key_a == key.a &&
             h.key_b == key.b && h.n_prims == n_prims && h.n_nodes >= 1 && h.n_nodes <= n_prims + 1;
   if (ok) {
     nodes.resize((size_t)h.n_nodes);
@@ -351,7 +351,7 @@ void cache_store(const std::string& path, CacheKey key, const std::vector<NodePa
   if (!f) return;
   CacheHeader h;
   std::memset(&h, 0, sizeof h);
-  std::memcpy(h.magic, "PTKBVH4", 8);
+  std::memcpy(h.magic, "PTKBVH5", 8);
   h.key_a = key.a; h.key_b = key.b;
   h.n_prims = (int32_t)order.size(); h.n_nodes = (int32_t)nodes.size();
   h.max_depth = max_depth; h.max_leaf = max_leaf;

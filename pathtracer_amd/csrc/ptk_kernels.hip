@@ -104,8 +104,16 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 #ifndef PTK_STEAL_UNITS
 #define PTK_STEAL_UNITS 1  // persistent render launches: a workgroup whose XCD has no units left takes other XCDs' units
 #endif
+// 1: every XCD renders one contiguous block of tile rows instead of every eighth row (experiment: each L2 then sees
+// one part of the image; measured on the 1.3M-triangle scene, see the tile-order notes in the design document).
+#ifndef PTK_ROWS_COMPACT
+#define PTK_ROWS_COMPACT 0
+#endif
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
+#endif
+#ifndef PTK_STACK_PREFETCH
+#define PTK_STACK_PREFETCH 1  // a node visit reads its stack's top entry before it asks for the node (0: where the visit ends)
 #endif
 #ifndef PTK_STACK_ROOM
 #define PTK_STACK_ROOM 8  // steps that the descend loop runs unchecked after one look at every lane's stack height
@@ -186,16 +194,14 @@ struct LdsStack {
   }
   // Branch-free on the usual path: the entry above the top is scratch, so v is always written there and only
   // counts if the top moves up.  The builder keeps trees shallower than DEPTH + OVER - 2 (ptk_upload_scene checks).
-  __device__ __forceinline__ uint32_t step(bool do_push, uint32_t v, bool do_pop)
+  // Start of a node visit: the top entry, which step() hands back at the end of the visit.  Read before the node's own
+  // loads are issued, it has long arrived when they have.
+  __device__ __forceinline__ uint32_t prefetch() const { return PTK_STACK_PREFETCH ? (any_beyond(top) ? read_at(top) : *top) : 0u; }
+  __device__ __forceinline__ uint32_t step(bool do_push, uint32_t v, bool do_pop, uint32_t t)
   {
-    uint32_t t;
-    if (any_beyond(top + kStep)) {
-      t = read_at(top);
-      write_at(top + kStep, v);
-    } else {
-      t = *top;
-      top[kStep] = v;
-    }
+    if (!PTK_STACK_PREFETCH) t = any_beyond(top) ? read_at(top) : *top;
+    if (any_beyond(top + kStep)) write_at(top + kStep, v);
+    else top[kStep] = v;
     // at most one of the two is set; a byte step of +-4 (lane-major) is an inline constant of the select
     const int step_words = do_push ? kStep : (do_pop ? -kStep : 0);
     top += step_words;
@@ -387,7 +393,9 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   int virt = xcd_remap(xcd + 8 * unit, n_units);
   int tile = virt / ra.chunks, chunk = virt - tile * ra.chunks;
   int tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
+#if !PTK_ROWS_COMPACT
   ty = interleave_rows(ty, ra.n_tiles / ra.tiles_x);
+#endif
 
   PathParams pp;
   pp.x0 = tx * kTile; pp.y0 = launch_row_to_image_row(ra, ty * kTile);

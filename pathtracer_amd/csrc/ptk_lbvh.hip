@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t
   nodes[i].child1 = c1;
 }
 
-// A box as the nodes store it: per axis, low grid plane | (high plane - low plane) << 16.
+// A box as the nodes store it: per axis, low grid plane | extent (grid_pack in ptk_layout.h).
 struct QBox {
   uint32_t x, y, z;
 };
@@ -131,15 +131,15 @@ struct QBox {
 __device__ inline uint32_t q_union(uint32_t a, uint32_t b)
 {
   const uint32_t lo_a = a & 0xffffu, lo_b = b & 0xffffu;
-  const uint32_t lo = min(lo_a, lo_b), hi = max(lo_a + (a >> 16), lo_b + (b >> 16));
-  return lo | ((hi - lo) << 16);
+  const uint32_t lo = min(lo_a, lo_b), hi = max(lo_a + grid_extent_steps(a), lo_b + grid_extent_steps(b));
+  return grid_pack(lo, hi - lo);
 }
 
 __device__ inline float q_half_area(const QBox& b, const BoxGrid& g)
 {
-  float dx = (float)(b.x >> 16) * g.scale[0];
-  float dy = (float)(b.y >> 16) * g.scale[1];
-  float dz = (float)(b.z >> 16) * g.scale[2];
+  float dx = (float)grid_extent_steps(b.x) * g.scale[0];
+  float dy = (float)grid_extent_steps(b.y) * g.scale[1];
+  float dz = (float)grid_extent_steps(b.z) * g.scale[2];
   return dx * dy + dy * dz + dz * dx;
 }
 

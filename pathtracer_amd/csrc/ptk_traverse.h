@@ -132,31 +132,6 @@ PTK_HD bool hit_box(float xlo, float ex, float ylo, float ey, float zlo, float e
   return tnear <= tfar;  // no slack needed: the builder pads every box well beyond the rounding of these products
 }
 
-// Experiment (-DPTK_TYPED_NODE_LOADS=1): fetch a node's boxes with three typed loads, which saves the twelve
-// conversions of a visit but makes it four memory instructions instead of two: measured 2-8 % slower.
-#ifndef PTK_TYPED_NODE_LOADS
-#define PTK_TYPED_NODE_LOADS 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-// Typed buffer load: 8 bytes holding four 16-bit unsigned integers arrive as four floats (the conversion is
-// done by the memory pipeline, exactly; measured to cost what a plain 8-byte load costs).
-typedef int ptk_v4i __attribute__((ext_vector_type(4)));
-typedef float ptk_v4f __attribute__((ext_vector_type(4)));
-__device__ ptk_v4f ptk_buffer_load_format_xyzw(ptk_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.format.v4f32");
-// Buffer resource over `bytes` bytes at `base`: no stride (offsets are bytes), destination select x, y, z, w,
-// number format USCALED (2), data format 16_16_16_16 (12).
-__device__ __forceinline__ ptk_v4i node_box_resource(const void* base, uint32_t bytes)
-{
-  const uint64_t a = (uint64_t)base;
-  ptk_v4i r;
-  r.x = (int)(uint32_t)a;
-  r.y = (int)(uint32_t)((a >> 32) & 0xffffu);
-  r.z = (int)bytes;
-  r.w = (int)(4u | (5u << 3) | (6u << 6) | (7u << 9) | (2u << 12) | (12u << 15));
-  return r;
-}
-#endif
-
 // ---------------------------------------------------------------------------------
 // Resumable traversal.  A lane's query is a small state (ray, closest hit so far, current
 // node) plus its stack; trav_inner() visits one inner node, trav_leaf() intersects one leaf.
@@ -164,9 +139,10 @@ __device__ __forceinline__ ptk_v4i node_box_resource(const void* base, uint32_t 
 // as separate uniform loops, and lets a lane whose query has finished pick up its next ray
 // while its neighbours are still traversing.
 //
-// Stack: reset(), pop() -> uint32_t, and step(do_push, v, do_pop) -> the top entry as it was before the
-// call, after which v has been pushed or the top popped as asked (never both).  reset() leaves kTravDone
-// at the bottom, so popping an exhausted stack yields the "finished" node.
+// Stack: reset(), pop() -> uint32_t, and step(do_push, v, do_pop, top) -> the top entry as it was before the
+// call, after which v has been pushed or the top popped as asked (never both); the last argument is what prefetch()
+// returned at the start of the node visit that ends in step() (the top entry: a stack in slow memory starts its read there).  reset() leaves
+// kTravDone at the bottom, so popping an exhausted stack yields the "finished" node.
 constexpr int32_t kTravDone = (int32_t)0x80000000;  // not a valid leaf code for < 2^28 primitives
 
 struct Traversal {
@@ -298,21 +274,13 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
 {
   // a 32-bit byte offset from the (wave-uniform) array base: one shift instead of 64-bit address arithmetic
   const uint32_t node_off = (uint32_t)tr.node * (uint32_t)sizeof(NodePair);
-#if defined(__HIP_DEVICE_COMPILE__) && PTK_TYPED_NODE_LOADS
-  const char* node_at = reinterpret_cast<const char*>(sc.nodes) + node_off;
-  const ptk_v4i boxes = node_box_resource(sc.nodes, (uint32_t)sc.n_nodes * (uint32_t)sizeof(NodePair));
-  const ptk_v4f bx = ptk_buffer_load_format_xyzw(boxes, (int)node_off, 0, 0);  // low plane and extent of child 0, of child 1
-  const ptk_v4f by = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 8, 0, 0);
-  const ptk_v4f bz = ptk_buffer_load_format_xyzw(boxes, (int)node_off + 16, 0, 0);
-  const int32_t child0 = *reinterpret_cast<const int32_t*>(node_at + 24), child1 = *reinterpret_cast<const int32_t*>(node_at + 28);
-#else
+  const uint32_t stack_top = st.prefetch();  // what step() below hands back, asked for before the node itself
   const NodePair nd = mem.node(sc, node_off);
   struct { float x, y, z, w; } bx, by, bz;
-  bx.x = (float)(nd.x0 & 0xffffu); bx.y = (float)(nd.x0 >> 16); bx.z = (float)(nd.x1 & 0xffffu); bx.w = (float)(nd.x1 >> 16);
-  by.x = (float)(nd.y0 & 0xffffu); by.y = (float)(nd.y0 >> 16); by.z = (float)(nd.y1 & 0xffffu); by.w = (float)(nd.y1 >> 16);
-  bz.x = (float)(nd.z0 & 0xffffu); bz.y = (float)(nd.z0 >> 16); bz.z = (float)(nd.z1 & 0xffffu); bz.w = (float)(nd.z1 >> 16);
+  bx.x = (float)(nd.x0 & 0xffffu); bx.y = grid_extent(nd.x0); bx.z = (float)(nd.x1 & 0xffffu); bx.w = grid_extent(nd.x1);
+  by.x = (float)(nd.y0 & 0xffffu); by.y = grid_extent(nd.y0); by.z = (float)(nd.y1 & 0xffffu); by.w = grid_extent(nd.y1);
+  bz.x = (float)(nd.z0 & 0xffffu); bz.y = grid_extent(nd.z0); bz.z = (float)(nd.z1 & 0xffffu); bz.w = grid_extent(nd.z1);
   const int32_t child0 = nd.child0, child1 = nd.child1;
-#endif
 #ifdef PTK_EXTRA_LOAD  // experiment: one more 16-byte cache access per node visit, result unused
   {
     // 1: at the lane's own node; 2: lanes 2k and 2k+1 read the two adjacent halves of lane 2k's node
@@ -350,7 +318,7 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   const bool closer1 = tn1 < tn0;
   const bool first1 = h1 && (!h0 || closer1);  // child 1 is the one to visit first
   const int32_t near = first1 ? child1 : child0, far = first1 ? child0 : child1;
-  const uint32_t top = st.step(both, (uint32_t)far, none);
+  const uint32_t top = st.step(both, (uint32_t)far, none, stack_top);
   tr.node = none ? (int32_t)top : near;
 }
 

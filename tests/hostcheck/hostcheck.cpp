@@ -26,9 +26,9 @@ struct HostStack {
     if (sp > high_water) high_water = sp;
   }
   uint32_t pop() { return data[--sp]; }
-  uint32_t step(bool do_push, uint32_t v, bool do_pop)
+  uint32_t prefetch() const { return data[sp - 1]; }
+  uint32_t step(bool do_push, uint32_t v, bool do_pop, uint32_t top)
   {
-    uint32_t top = data[sp - 1];
     if (do_push) push(v);
     if (do_pop) sp--;
     return top;
@@ -75,7 +75,7 @@ void hc_tree_check(void* h, int64_t* out)
     const uint32_t w[3] = {wx, wy, wz};
     for (int a = 0; a < 3; a++) {
       t.lo[a] = (double)g.origin[a] + (double)(w[a] & 0xffffu) * (double)g.scale[a];
-      t.hi[a] = (double)g.origin[a] + (double)((w[a] & 0xffffu) + (w[a] >> 16)) * (double)g.scale[a];  // low plane + extent
+      t.hi[a] = (double)g.origin[a] + ((double)(w[a] & 0xffffu) + (double)grid_extent_steps(w[a])) * (double)g.scale[a];  // low plane + extent (what the traversal sees is not below it)
     }
   };
   const NodePair& root = hs.nodes[0];

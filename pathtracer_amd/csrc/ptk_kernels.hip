@@ -413,29 +413,29 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   path_init(ps);
   uint32_t next_item = 0;  // wave-uniform: only ever changed where all 64 lanes are active
 
-  // Hand the next work items, in lane order, to the lanes that ask for one; repeat while a lane
-  // was given an item that needs no query (a pixel slot outside the image).
+  // Hand the next work items, in lane order, to the lanes that ask for one.  Returns whether the lane is still free
+  // afterwards: its item needed no query (a pixel slot outside the image) - it then asks again in the next refill
+  // phase rather than in a loop here, which would cost every refill the register copies of a loop around the whole
+  // path state for the sake of the tiles on the image's edge.
   // Path segments and queries started by this wave, counted for the whole wave at once where its phases end
   // (a ballot and a scalar add) instead of in a register of every lane: the per-lane counts of `cnt` are left
   // unread in this kernel, so the compiler drops them.  Camera rays are counted by the host (rows x width x samples).
   // (The deep-tree form has the registers and is 1 % faster with the per-lane counts, so it keeps them.)
-  auto refill = [&](bool need) {
-    for (;;) {
-      unsigned long long m = __ballot(need);
-      if (m == 0ull) break;
-      uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      uint32_t item = next_item + rank;
-      next_item += (uint32_t)__popcll(m);
-      const bool asked = need;
-      if (need) need = path_begin_item(ps, st, sc, cam, pp, item, cnt);
-      if (kWaveCounts) {
-        const unsigned long long began = (unsigned long long)__popcll(__ballot(asked && !need && ps.alive));  // a primary ray is on its way
-        wave_segments += began;
-        wave_queries += began;
-      }
+  auto refill = [&](bool need) -> bool {
+    const unsigned long long m = __ballot(need);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint32_t item = next_item + rank;
+    next_item += (uint32_t)__popcll(m);
+    bool still = false;
+    if (need) still = path_begin_item(ps, st, sc, cam, pp, item, cnt);
+    if (kWaveCounts) {
+      const unsigned long long began = (unsigned long long)__popcll(__ballot(need && !still && ps.alive));  // a primary ray is on its way
+      wave_segments += began;
+      wave_queries += began;
     }
+    return still;
   };
-  refill(true);
+  bool need = refill(true);  // this lane's path has ended (or never began) and it has not been given a new work item yet
 
   // Every lane keeps one query in flight.  The wave alternates uniform phases, each run only when
   // enough lanes want it (or when no lane is traversing any more, so that everything drains):
@@ -451,7 +451,6 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   // clock cycles the wave spends in each phase (s_memtime; the stamps themselves cost about a tenth of the run)
   PTK_PHASE(unsigned long long tph[5] = {0, 0, 0, 0, 0}; unsigned long long tmark = __builtin_amdgcn_s_memtime();)
 #define PTK_PHASE_CLOCK(k) PTK_PHASE({ unsigned long long tnow = __builtin_amdgcn_s_memtime(); tph[k] += tnow - tmark; tmark = tnow; })
-  bool need = false;  // this lane's path has ended and it has not been given a new work item yet
   __builtin_amdgcn_s_setprio(PTK_PRIO_DESCEND);
   int32_t held = kTravDone;  // a leaf the lane has reached but not intersected yet (kTravDone: none)
   for (;;) {
@@ -472,6 +471,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       if (want) trav_inner<S, STATS, Mem>(ps.tr, s, sc, cnt, mem);
       return false;
     };
+    PTK_MARK("descend");
     for (;;) {
       if (SPILL && st.roomy()) {
         auto fast = st.unchecked();
@@ -485,6 +485,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       }
     }
     PTK_PHASE_CLOCK(0)
+    PTK_MARK("leaves");
     __builtin_amdgcn_s_setprio(PTK_PRIO_LEAF);
     PTK_PHASE(ph[2]++; ph[3] += __popcll(__ballot(held != kTravDone)); ph[4] += __popcll(__ballot(trav_at_inner(ps.tr)));)
     if (held != kTravDone) {
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     }
     if (trav_at_leaf(ps.tr)) trav_leaf<LdsStack, STATS, Mem>(ps.tr, st, sc, cnt, mem);
     PTK_PHASE_CLOCK(1)
+    PTK_MARK("decide");
     __builtin_amdgcn_s_setprio(PTK_PRIO_SHADE);
     const bool done = trav_done(ps.tr);
     const bool waiting = ps.alive && done && !need;
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
     const bool idle = __ballot(!done) == 0ull;  // no lane is traversing: everything that waits must run now
     if (idle && n_lit + n_shade + __popcll(__ballot(need)) == 0) break;
     if (n_lit >= PTK_LIT_MIN || (idle && n_lit > 0)) {
+      PTK_MARK("lit");
       bool goes_on = false;
       if (lit) {
         goes_on = !path_consume_shadow(ps, st, sc, fl, pp, cnt, park);
@@ -512,9 +515,11 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
         wave_queries += began;
       }
     }
+    PTK_MARK("decide2");
     PTK_PHASE_CLOCK(2)
     if (n_shade >= PTK_SHADE_MIN || (idle && n_shade > 0)) {
       PTK_PHASE(ph[5]++; ph[6] += n_shade;)
+      PTK_MARK("shade");
       bool goes_on = false;
       if (shade) {
         goes_on = !path_shade<LdsStack, Mem, Park>(ps, st, sc, fl, pp, cnt, mem, park);
@@ -525,11 +530,13 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
         wave_segments += (unsigned long long)__popcll(__ballot(goes_on && !ps.shadow));  // the next segment
       }
     }
+    PTK_MARK("decide3");
     PTK_PHASE_CLOCK(3)
     const int n_need = __popcll(__ballot(need));
     if (n_need >= PTK_ITEM_MIN || (idle && n_need > 0)) {
-      refill(need);
-      need = false;
+      PTK_MARK("refill");
+      need = refill(need);
+      PTK_MARK("refill_end");
     }
     PTK_PHASE_CLOCK(4)
     __builtin_amdgcn_s_setprio(PTK_PRIO_DESCEND);

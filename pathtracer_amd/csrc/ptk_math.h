@@ -14,6 +14,14 @@
 #define PTK_HD inline
 #endif
 
+// Analysis aid: -DPTK_MARKERS puts named comments into the compiler's assembly output (they constrain its scheduling a
+// little, so normal builds leave them out); tools/asm_regions.py counts the instructions between them.
+#if defined(PTK_MARKERS) && defined(__HIP_DEVICE_COMPILE__)
+#define PTK_MARK(name) asm volatile("; PTK_MARK " name)
+#else
+#define PTK_MARK(name)
+#endif
+
 namespace ptk {
 
 struct v3 {

@@ -487,6 +487,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     ps.L += ps.beta * background(sc, d);  // src/renderer.cpp:67-69
     return true;
   }
+  PTK_MARK("shade.surface");
   Surface s;
   make_surface(sc, o, d, ps.tr.hit, s, mem);
   const auto& m = mem.material(sc, s.material);
@@ -494,8 +495,10 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     ps.L += ps.beta * (V3(s.normal.x + 1.0f, s.normal.y + 1.0f, s.normal.z + 1.0f) * 0.5f);
     return true;
   }
+  PTK_MARK("shade.albedo");
   v3 albedo = surface_albedo(sc, m, s);
   v3 emission = ld3(m.emission);
+  PTK_MARK("shade.rr");
   float rr_weight = 1.0f;
   if (fl.russian_roulette && ps.depth() > 3) {  // src/renderer.cpp:78-90
     float p = luma(albedo);
@@ -505,9 +508,12 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     }
     rr_weight = frcp(p);
   }
+  PTK_MARK("shade.frame");
   Frame fr = make_frame(s.normal);
   v3 wo = to_local(fr, -d);
+  PTK_MARK("shade.sample");
   v3 wi = bsdf_sample(fl, m, s.inside, wo, ps.g);
+  PTK_MARK("shade.eval");
   bool specular = (m.flags & kMatSpecular) != 0;
   v3 scale = ps.beta * rr_weight;
   if (!fl.direct_light_sampling || ps.depth() == 0 || specular || ps.prev_specular) ps.L += scale * emission;
@@ -518,6 +524,7 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   v3 to_light, pending;
   float distance, t_stop;
   uint32_t light_id;
+  PTK_MARK("shade.nee");
   if (fl.direct_light_sampling && !specular &&
       nee_setup(ps, sc, fl, m, s, albedo, d, scale, to_light, distance, t_stop, light_id, pending, mem)) {
     ps.shadow = true;

@@ -4,9 +4,12 @@
 
     tools/make_traffic.py <summary.json> <workload_WxH_SPPspp> [traffic.json]
 
-rocprofv3 gives FETCH_SIZE / WRITE_SIZE in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-byte requests as
-64 bytes, so reads are doubled (the correction measured for wide coalesced reads; the 32-byte node and 40-byte
-triangle gathers of this kernel are not separately calibrated, which makes the figure an upper bound).
+rocprofv3 gives FETCH_SIZE / WRITE_SIZE in KiB per dispatch.  On gfx950 FETCH_SIZE tallies every request of the L2 to
+the fabric at 64 bytes, and every such request is a whole 128-byte line - for wide coalesced reads AND for the 16-byte
+per-lane gathers of this kernel (tools/ubench/fetch_calib.hip, profiles/r3_ubench_fetch_calib.txt: one request per
+missed line whether a lane takes 16 bytes of it or both halves, no 32-byte requests, and the gather moves lines at the
+streaming rate only if a line is 128 bytes), so reads are doubled.  The figure is what crosses from the fabric into
+the L2s: hits in the 256 MB Infinity Cache are in it.
 SQ cycle counters are in units of four cycles and summed over all waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
 import json, sys
 

@@ -112,6 +112,15 @@ constexpr int kDescendMin = PTK_DESCEND_MIN;
 #ifndef PTK_STACK_LANE_MAJOR
 #define PTK_STACK_LANE_MAJOR 1
 #endif
+// 1: the phases of the render loop only store their lanes' new queries; the arithmetic that starts a query (three
+// reciprocals, the slab constants, the stack) runs once per pass of the loop for all of them (trav_start).
+#ifndef PTK_DEFER_START
+#define PTK_DEFER_START 1
+#endif
+// n > 1: a step of the descend loop visits up to n nodes per lane before the wave looks at its lanes again
+#ifndef PTK_DESCEND_VISITS
+#define PTK_DESCEND_VISITS 2
+#endif
 #ifndef PTK_STACK_PREFETCH
 #define PTK_STACK_PREFETCH 1  // a node visit reads its stack's top entry before it asks for the node (0: where the visit ends)
 #endif
@@ -324,6 +333,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   constexpr int kLdsDepth = DEEP ? kStackDepth : (TINY ? kStackDepthTiny : (TABLES ? kStackDepthTables : kStackDepthShallow));
   using LdsStack = ptk::LdsStack<kLdsDepth, SPILL ? kStackDepth - kLdsDepth : 0>;
   using Mem = typename std::conditional<TINY, LdsMem, typename std::conditional<TABLES, TablesMem, GlobalMem>::type>::type;
+  constexpr bool DEFER = PTK_DEFER_START != 0;
   constexpr bool PARK = PTK_PARK && !DEEP && !TINY;  // the waiting vectors of a path in LDS (LdsPark)
   static_assert(!TABLES || kStackDepthTables > (PARK ? 13 : 19) || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes + (PARK ? kParkBytes : 0) <= 5 * 1280,
                 "stack, pixel sums, tables (and parked vectors) share five LDS granules");
@@ -421,21 +431,24 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   // (a ballot and a scalar add) instead of in a register of every lane: the per-lane counts of `cnt` are left
   // unread in this kernel, so the compiler drops them.  Camera rays are counted by the host (rows x width x samples).
   // (The deep-tree form has the registers and is 1 % faster with the per-lane counts, so it keeps them.)
+  bool started = false;  // DEFER: this lane was given a query in this pass of the loop and trav_start() has not run for it yet
   auto refill = [&](bool need) -> bool {
     const unsigned long long m = __ballot(need);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     const uint32_t item = next_item + rank;
     next_item += (uint32_t)__popcll(m);
     bool still = false;
-    if (need) still = path_begin_item(ps, st, sc, cam, pp, item, cnt);
+    if (need) still = path_begin_item<LdsStack, DEFER>(ps, st, sc, cam, pp, item, cnt);
     if (kWaveCounts) {
       const unsigned long long began = (unsigned long long)__popcll(__ballot(need && !still && ps.alive));  // a primary ray is on its way
       wave_segments += began;
       wave_queries += began;
     }
+    if (DEFER) started = started || (need && !still && ps.alive);
     return still;
   };
   bool need = refill(true);  // this lane's path has ended (or never began) and it has not been given a new work item yet
+  if (DEFER) { if (started) trav_start(ps.tr, st, sc); started = false; }
 
   // Every lane keeps one query in flight.  The wave alternates uniform phases, each run only when
   // enough lanes want it (or when no lane is traversing any more, so that everything drains):
@@ -466,9 +479,15 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       const int n_want = __popcll(__ballot(want));
       // few lanes at an inner node: they wait for the leaf phase to send more lanes back, unless no leaf is held
       const bool any_held = __ballot(held != kTravDone) != 0ull;
-      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) return true;  // evaluated eagerly: one branch instead of three
+      // Evaluated eagerly: one branch instead of three.  (The compiler forms "n_want < kDescendMin" with a 64-bit VECTOR
+      // compare; the same test spelled out as two scalar instructions makes the loop 1 % slower: a wave issues its
+      // instructions one after the other whatever unit they are for, and the scalar chain of a step is the longer one.)
+      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) return true;
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<S, STATS, Mem>(ps.tr, s, sc, cnt, mem);
+#pragma unroll
+      for (int extra = 1; extra < PTK_DESCEND_VISITS; extra++)
+        if (trav_at_inner(ps.tr)) trav_inner<S, STATS, Mem>(ps.tr, s, sc, cnt, mem);
       return false;
     };
     PTK_MARK("descend");
@@ -477,7 +496,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
         auto fast = st.unchecked();
         bool leave = false;
 #pragma nounroll
-        for (int k = 0; k < LdsStack::kRoom && !leave; k++) leave = descend_step(fast);
+        for (int k = 0; k < LdsStack::kRoom / PTK_DESCEND_VISITS && !leave; k++) leave = descend_step(fast);  // at most kRoom pushes
         st.top = fast.top;
         if (leave) break;
       } else if (descend_step(st)) {
@@ -506,9 +525,10 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       PTK_MARK("lit");
       bool goes_on = false;
       if (lit) {
-        goes_on = !path_consume_shadow(ps, st, sc, fl, pp, cnt, park);
+        goes_on = !path_consume_shadow<LdsStack, Park, DEFER>(ps, st, sc, fl, pp, cnt, park);
         if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
       }
+      if (DEFER) started = started || goes_on;
       if (kWaveCounts) {
         const unsigned long long began = (unsigned long long)__popcll(__ballot(goes_on));  // the path's next segment
         wave_segments += began;
@@ -522,9 +542,10 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       PTK_MARK("shade");
       bool goes_on = false;
       if (shade) {
-        goes_on = !path_shade<LdsStack, Mem, Park>(ps, st, sc, fl, pp, cnt, mem, park);
+        goes_on = !path_shade<LdsStack, Mem, Park, DEFER>(ps, st, sc, fl, pp, cnt, mem, park);
         if (!goes_on) { acc.add(ps.slot(), ps.L); need = true; }
       }
+      if (DEFER) started = started || goes_on;
       if (kWaveCounts) {
         wave_queries += (unsigned long long)__popcll(__ballot(goes_on));                 // a shadow ray or the next segment
         wave_segments += (unsigned long long)__popcll(__ballot(goes_on && !ps.shadow));  // the next segment
@@ -538,6 +559,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       need = refill(need);
       PTK_MARK("refill_end");
     }
+    if (DEFER) { if (started) trav_start(ps.tr, st, sc); started = false; }
     PTK_PHASE_CLOCK(4)
     __builtin_amdgcn_s_setprio(PTK_PRIO_DESCEND);
   }

@@ -361,7 +361,7 @@ PTK_HD void path_init(PathState& ps)
 // Give a free lane work item `item`.  Returns true when the lane is still free afterwards (the item
 // lay outside the image, or needed no query) and wants another item; false when the lane has a
 // query in flight or the items have run out (then ps.alive is false).
-template <class Stack>
+template <class Stack, bool DEFER = false>
 PTK_HD bool path_begin_item(PathState& ps, Stack& st, const SceneView& sc, const CameraView& cam,
                             const PathParams& pp, uint32_t item, Counters& cnt)
 {
@@ -387,13 +387,13 @@ PTK_HD bool path_begin_item(PathState& ps, Stack& st, const SceneView& sc, const
   cnt.segments++;
   cnt.queries++;
   // a camera far outside the scene: start the traversal in front of the scene's bounds (camera_entry_shift; d is a unit vector)
-  trav_begin(ps.tr, st, sc, o + d * pp.camera_shift, d, kTMax, kNoPrim);
+  trav_begin<Stack, DEFER>(ps.tr, st, sc, o + d * pp.camera_shift, d, kTMax, kNoPrim);
   return false;
 }
 
 // Start the path segment that leaves the current vertex (on primitive from_id) in direction d.
 // Returns true when the bounce limit ends the path instead.
-template <class Stack>
+template <class Stack, bool DEFER = false>
 PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, const PathParams& pp, const FlagView& fl,
                               v3 d, uint32_t from_id, Counters& cnt)
 {
@@ -402,7 +402,7 @@ PTK_HD bool path_next_segment(PathState& ps, Stack& st, const SceneView& sc, con
   if (!fl.indirect_light_sampling || ps.depth() >= pp.max_bounce) return true;
   cnt.segments++;
   cnt.queries++;
-  trav_begin(ps.tr, st, sc, ps.tr.o, d, kTMax, from_id);
+  trav_begin<Stack, DEFER>(ps.tr, st, sc, ps.tr.o, d, kTMax, from_id);
   return false;
 }
 
@@ -475,7 +475,7 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
 }
 
 // A path segment's query has finished: shade the vertex it found.  Returns true when the path ends here.
-template <class Stack, class Mem = GlobalMem, class Park = ParkInState>
+template <class Stack, class Mem = GlobalMem, class Park = ParkInState, bool DEFER = false>
 PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
                        Counters& cnt, const Mem& mem = Mem(), const Park& park = Park())
 {
@@ -532,15 +532,15 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
     cnt.queries++;
     // the light is at `distance`: nothing farther can be the closest hit that counts
     // the light the ray must reach stays in the query (Traversal::target) until the result is used
-    trav_begin(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, light_id, t_stop);
+    trav_begin<Stack, DEFER>(ps.tr, st, sc, s.point, to_light, distance * 1.001f + 1e-3f, s.id, light_id, t_stop);
     return false;
   }
-  return path_next_segment(ps, st, sc, pp, fl, next_d, s.id, cnt);
+  return path_next_segment<Stack, DEFER>(ps, st, sc, pp, fl, next_d, s.id, cnt);
 }
 
 // A shadow ray's query has finished: add the light's contribution if the light is what it reached,
 // then start the path's next segment.  Returns true when the path ends here.
-template <class Stack, class Park = ParkInState>
+template <class Stack, class Park = ParkInState, bool DEFER = false>
 PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, const FlagView& fl, const PathParams& pp,
                                 Counters& cnt, const Park& park = Park())
 {
@@ -548,7 +548,7 @@ PTK_HD bool path_consume_shadow(PathState& ps, Stack& st, const SceneView& sc, c
   park.load(ps, pending, next_d);
   if (ps.tr.hit.id == ps.tr.target) ps.L += pending;  // src/renderer.cpp:146
   // the shadow ray left the vertex the next segment leaves: same origin, same primitive to skip
-  return path_next_segment(ps, st, sc, pp, fl, next_d, ps.tr.skip_id, cnt);
+  return path_next_segment<Stack, DEFER>(ps, st, sc, pp, fl, next_d, ps.tr.skip_id, cnt);
 }
 
 // The lane's query has finished: use its result and set up the next query of the path.  Returns

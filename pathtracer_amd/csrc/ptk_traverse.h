@@ -161,13 +161,23 @@ PTK_HD bool trav_done(const Traversal& tr) { return tr.node == kTravDone; }
 PTK_HD bool trav_at_inner(const Traversal& tr) { return tr.node >= 0; }
 PTK_HD bool trav_at_leaf(const Traversal& tr) { return tr.node < 0 && tr.node != kTravDone; }
 
-template <class Stack>
-PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id,
-                       uint32_t target = kNoPrim, float t_stop = -1.0f)
+// A query starts in two parts, so that a kernel whose phases each set up queries for some lanes can run the second,
+// arithmetic part once for all of them: trav_set_query() only stores the ray and its limits, trav_start() derives
+// what the node visits need from them and empties the stack.  trav_begin() is both.
+PTK_HD void trav_set_query(Traversal& tr, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id,
+                           uint32_t target = kNoPrim, float t_stop = -1.0f)
 {
   tr.target = target;
   tr.t_stop = t_stop;
   tr.o = o; tr.d = d;
+  tr.hit.t = tmax;
+  tr.skip_id = skip_id;
+  tr.node = sc.n_prims > 0 ? 0 : kTravDone;
+}
+template <class Stack>
+PTK_HD void trav_start(Traversal& tr, Stack& st, const SceneView& sc)
+{
+  const v3 o = tr.o, d = tr.d;
   // 1/d is kept finite: with an infinite 1/d the fused form below would turn "inf - inf" into NaN for one
   // plane of a slab that contains the origin.  1e20 keeps every product far inside the float range.
   const float big = 1e20f;
@@ -175,12 +185,16 @@ PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d
                    fmaxf(fminf(frcp(d.z), big), -big));
   tr.inv = V3(rd.x * sc.grid.scale[0], rd.y * sc.grid.scale[1], rd.z * sc.grid.scale[2]);
   tr.oi = V3((o.x - sc.grid.origin[0]) * rd.x, (o.y - sc.grid.origin[1]) * rd.y, (o.z - sc.grid.origin[2]) * rd.z);
-  tr.hit.t = tmax;
   tr.hit.id = kNoPrim;
   tr.hit.u = tr.hit.v = 0.0f;
-  tr.skip_id = skip_id;
   st.reset();
-  tr.node = sc.n_prims > 0 ? 0 : kTravDone;
+}
+template <class Stack, bool DEFER = false>
+PTK_HD void trav_begin(Traversal& tr, Stack& st, const SceneView& sc, v3 o, v3 d, float tmax, uint32_t skip_id,
+                       uint32_t target = kNoPrim, float t_stop = -1.0f)
+{
+  trav_set_query(tr, sc, o, d, tmax, skip_id, target, t_stop);
+  if (!DEFER) trav_start(tr, st, sc);  // DEFER: the caller runs trav_start() before the query's first node visit
 }
 
 // How far a ray that starts far outside the scene can be advanced before it meets the scene's bounds.

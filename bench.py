@@ -256,7 +256,8 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu, split
         "value": queries / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / args.steps * 1e3,
         "config": {"workload": f"{name}: {WORKLOADS[name]}; {width}x{height}, {frame_spp} spp per frame"
                                + (f" ({mine} on this GPU)" if world > 1 and split == "spp" else "") + f", {bounces} bounces",
-                   "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"],
+                   "triangles": int(sd.n_triangles), "spheres": int(sd.n_spheres), "bvh_nodes": info["n_nodes"], "bvh_depth": info["max_depth"],
+                   "traversal_kind": info["traversal_kind"],
                    "bvh_builder": "device" if info["builder"] else "host",
                    "scene_upload_ms": round(info["upload_ms"], 2), "device_build_ms": round(info["device_build_ms"], 3),
                    "split": (f"{split} split, {merge.describe()}" if world > 1 else "none"),

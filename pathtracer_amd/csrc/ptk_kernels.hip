@@ -329,8 +329,8 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
 {
   constexpr bool DEEP = FORM == kFormDeep, TINY = FORM == kFormTiny;
   constexpr bool TABLES = FORM == kFormShallowTables || FORM == kFormSpillTables;  // material and light tables in LDS
-  constexpr bool SPILL = FORM == kFormSpill || FORM == kFormSpillTables;           // stack entries beyond the LDS part
-  constexpr int kLdsDepth = DEEP ? kStackDepth : (TINY ? kStackDepthTiny : (TABLES ? kStackDepthTables : kStackDepthShallow));
+  constexpr bool SPILL = FORM == kFormSpill || FORM == kFormSpillTables || (DEEP && kStackDepthDeep < kStackDepth);  // stack entries beyond the LDS part
+  constexpr int kLdsDepth = DEEP ? kStackDepthDeep : (TINY ? kStackDepthTiny : (TABLES ? kStackDepthTables : kStackDepthShallow));
   using LdsStack = ptk::LdsStack<kLdsDepth, SPILL ? kStackDepth - kLdsDepth : 0>;
   using Mem = typename std::conditional<TINY, LdsMem, typename std::conditional<TABLES, TablesMem, GlobalMem>::type>::type;
   constexpr bool DEFER = PTK_DEFER_START != 0;
@@ -648,7 +648,8 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
                                                            ptk_hit* __restrict__ hits, unsigned long long* counters, int run)
 {
   // (a test build with a very short shallow stack keeps the full one here: a lane's stack region also stages its hit record)
-  using LdsStack = ptk::LdsStack<(DEEP || kStackDepthShallow < 16) ? kStackDepth : kStackDepthShallow>;
+  constexpr int kLdsDepth = (DEEP || kStackDepthShallow < 16) ? kStackDepthDeep : kStackDepthShallow;
+  using LdsStack = ptk::LdsStack<kLdsDepth, DEEP ? kStackDepth - kLdsDepth : 0>;  // deep trees: overflow words, every operation checked
   __shared__ uint32_t lds_stack[LdsStack::kDepth * kBlock];
   __shared__ uint32_t lds_finished[kBlock];  // the lanes whose records wait to be written out, in rank order
 #ifdef PTK_INTERSECT_LDS_PAD
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
   if (n < 0) lds_pad[threadIdx.x] = 1u;  // never true: keeps the array
 #endif
   LdsStack st;
-  st.attach(lds_stack, (int)threadIdx.x);
+  volatile uint32_t stack_over[LdsStack::kOver];
+  st.attach(lds_stack, (int)threadIdx.x, stack_over);
   const uint32_t lane = threadIdx.x;
   Counters cnt = {0, 0, 0, 0, 0};
   // The launch holds one round of resident waves (launch_intersect): every further round of workgroups was

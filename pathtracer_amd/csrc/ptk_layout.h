@@ -11,19 +11,29 @@ namespace ptk {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kMaxLeafSize = 4;   // primitives per BVH leaf
-// Per-lane traversal stack entries: a sentinel, one per tree level, one of scratch.  LDS is handed out in
-// granules of 1280 bytes and a one-wave workgroup also keeps its tile's pixel sums (768 bytes) there, so the
-// stack decides how many waves a CU's 160 KB can hold:
-//   deep    27 entries x 64 lanes x 4 bytes + sums = 7680 bytes = 6 granules: 20 waves per CU, 5 per SIMD;
-//           trees up to 25 levels (28 entries no longer fit: measured, back to the 4-wave rate)
+// Per-lane traversal stack entries: a sentinel, one per tree level, one of scratch.  kStackDepth is the most a stack
+// can hold, and so what bounds the depth of a tree (kMaxTreeDepth); how many of the entries live in LDS depends on
+// the kernel form, the rest are overflow words in the lane's private memory (LdsStack in ptk_kernels.hip).  LDS is
+// handed out in granules of 1280 bytes and a one-wave workgroup also keeps its tile's pixel sums (768 bytes) there,
+// so the LDS part decides how many waves a CU's 160 KB can hold:
+//   deep    27 entries x 64 lanes x 4 bytes + sums = 7680 bytes = 6 granules: 20 waves per CU, 5 per SIMD
+//           (28 entries no longer fit: measured, back to the 4-wave rate); the older form for trees of more than 20
+//           levels, kept for comparison
 //   shallow 22 entries + sums = 6400 bytes = 5 granules: 24 waves per CU, 6 per SIMD (the kernel is then built
-//           for 80 vector registers instead of 96); trees up to 20 levels.  The sixth wave is worth 5-11 % on
-//           the 82k-triangle scenes; capping the 1.3M-triangle scene's tree at 20 levels to get it costs 12 %.
-// The kernels exist in both forms and the scene's tree depth picks one.
+//           for 80 vector registers instead of 96); trees up to 20 levels without overflow words.  The sixth wave is
+//           worth 5-11 % on the 82k-triangle scenes; capping the 1.3M-triangle scene's tree at 20 levels to get it
+//           costs 12 %.
+// The kernels exist in these forms and the scene's tree depth picks one.  The depth limit is well above what a
+// balanced tree of the largest scenes needs (1.3M triangles: 21 levels): both builders fall back to median splits
+// where it binds, and with a limit of 25 that was where more than half of that scene's leaves ended up.
 #ifndef PTK_STACK_DEPTH
-#define PTK_STACK_DEPTH 27
+#define PTK_STACK_DEPTH 34
 #endif
-constexpr int kStackDepth = PTK_STACK_DEPTH;   // deep form: the largest stack
+constexpr int kStackDepth = PTK_STACK_DEPTH;   // the largest stack, LDS part and overflow words together
+#ifndef PTK_STACK_DEPTH_DEEP
+#define PTK_STACK_DEPTH_DEEP 27
+#endif
+constexpr int kStackDepthDeep = PTK_STACK_DEPTH_DEEP < PTK_STACK_DEPTH ? PTK_STACK_DEPTH_DEEP : PTK_STACK_DEPTH;  // deep form: entries in LDS
 #ifndef PTK_STACK_DEPTH_SHALLOW
 #define PTK_STACK_DEPTH_SHALLOW 22
 #endif

@@ -19,6 +19,8 @@
 //      (from the subtree sizes the fitting pass left); compact_kernel moves them there and renumbers the links; gather_kernel: primitive records into leaf order.
 #include "ptk_lbvh.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>  // rocprim headers use memset without including it
 #include <vector>
 
@@ -82,9 +84,30 @@ __device__ inline int median_levels(uint32_t n)
 __device__ inline int32_t leaf_link(uint32_t first, uint32_t count) { return (int32_t) ~((first << 3) | (count - 1u)); }
 
 // Nodes [begin, end) are the inner nodes at `depth`; each holds a range of at least two primitives.
+// Ranges of at most this many primitives are not split where a key bit flips but where the surface-area heuristic is
+// lowest among ALL positions of the (sorted) range: a sweep from the right stores the area of every suffix's box, a
+// sweep from the left prices every position.  Bit flips are spatial medians; near the leaves, where most of a ray's
+// node visits and all of its primitive tests happen, they leave boxes that overlap more than they have to.
+#ifndef PTK_LBVH_SAH_RANGE
+#define PTK_LBVH_SAH_RANGE 64
+#endif
+constexpr uint32_t kSahRange = PTK_LBVH_SAH_RANGE;
+
+struct FBox {
+  float lo[3], hi[3];
+  __device__ void reset() { for (int k = 0; k < 3; k++) { lo[k] = 3.0e38f; hi[k] = -3.0e38f; } }
+  __device__ void add(const float* b) { for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); } }
+  __device__ float half_area() const
+  {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
 __global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t* __restrict__ keys, BuildRange* ranges,
                                                                   NodePair* nodes, uint32_t begin, uint32_t end, int depth,
-                                                                  uint32_t* counter)
+                                                                  uint32_t* counter, const float* __restrict__ boxes,
+                                                                  const uint32_t* __restrict__ order)
 {
   uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= end) return;
@@ -106,6 +129,25 @@ __global__ __launch_bounds__(kBuildBlock) void split_level_kernel(const uint64_t
     if (depth + 1 + median_levels(big) > kMaxTreeDepth) by_key = false;
   }
   if (!by_key) mid = a + (r.count + 1u) / 2u;
+  if (kSahRange > 0u && r.count > 2u && r.count <= kSahRange) {
+    float suffix[kSahRange > 0u ? kSahRange : 1u];  // suffix[k]: half the surface area of the box of primitives a + k .. b
+    FBox acc;
+    acc.reset();
+    for (uint32_t k = r.count - 1u; k >= 1u; k--) {
+      acc.add(boxes + 6 * (size_t)order[a + k]);
+      suffix[k] = acc.half_area();
+    }
+    acc.reset();
+    float best = 3.0e38f;
+    uint32_t best_k = 0u;
+    for (uint32_t k = 1u; k < r.count; k++) {
+      acc.add(boxes + 6 * (size_t)order[a + k - 1u]);
+      const float cost = acc.half_area() * (float)k + suffix[k] * (float)(r.count - k);
+      if (cost < best) { best = cost; best_k = k; }
+    }
+    const uint32_t big = best_k > r.count - best_k ? best_k : r.count - best_k;
+    if (best_k > 0u && depth + 1 + median_levels(big) <= kMaxTreeDepth) mid = a + best_k;
+  }
   const uint32_t n0 = mid - a, n1 = r.count - n0;
   // A part becomes a leaf when it is one primitive, or when it is small enough for a leaf and the depth limit
   // leaves no room to split it down to single primitives.  Otherwise it is split further; the fitting pass
@@ -148,6 +190,13 @@ constexpr float kTraversalCost = 1.0f, kIntersectCost = 1.2f;  // the host build
 #define PTK_LBVH_MERGE_BIAS 1.0f
 #endif
 constexpr float kMergeBias = PTK_LBVH_MERGE_BIAS;  // < 1: fewer, smaller leaves
+// Largest leaf that merging may form.  (Leaves of up to kMaxLeafSize primitives still arise where the depth limit
+// leaves no room to split further.)  A wave's leaf phase takes as many passes as its lane with the most primitives
+// to test, so a few large leaves among many small ones cost every lane of the wave.
+#ifndef PTK_LBVH_MERGED_LEAF_MAX
+#define PTK_LBVH_MERGED_LEAF_MAX 4
+#endif
+constexpr uint32_t kMergedLeafMax = PTK_LBVH_MERGED_LEAF_MAX;
 
 // Box of the child behind `link`.  An inner child whose own children are both leaves, of at most
 // kMaxLeafSize primitives together, is replaced by one leaf when testing all of them costs no more
@@ -175,7 +224,7 @@ __device__ inline QBox child_box(int32_t& link, const float* __restrict__ boxes,
       const uint32_t l0 = ~(uint32_t)c.child0, l1 = ~(uint32_t)c.child1;
       const uint32_t n0 = (l0 & 7u) + 1u, n1 = (l1 & 7u) + 1u;
       // one leaf needs one range: l1 has to start where l0 ends (always so unless regroup() moved a leaf here)
-      if (n0 + n1 <= (uint32_t)kMaxLeafSize && (l1 >> 3) == (l0 >> 3) + n0) {
+      if (n0 + n1 <= kMergedLeafMax && (l1 >> 3) == (l0 >> 3) + n0) {
         const float a = q_half_area(r, g);
         const float split = kTraversalCost * a + kIntersectCost * (q_half_area(b0, g) * (float)n0 + q_half_area(b1, g) * (float)n1);
         const float leaf = kIntersectCost * a * (float)(n0 + n1);
@@ -359,7 +408,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   int depth = 0;
   while (begin < end) {
     if (depth >= kMaxTreeDepth) return "internal: device tree deeper than the traversal stack allows";
-    split_level_kernel<<<blocks_for(end - begin), kBuildBlock, 0, stream>>>(keys, ranges, nodes_full, begin, end, depth, counter);
+    split_level_kernel<<<blocks_for(end - begin), kBuildBlock, 0, stream>>>(keys, ranges, nodes_full, begin, end, depth, counter, d_boxes, order);
     LBVH_HIP(hipGetLastError());
     uint32_t total = 0;
     LBVH_HIP(hipMemcpyAsync(&total, counter, sizeof total, hipMemcpyDeviceToHost, stream));
@@ -410,6 +459,29 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
     (void)hipFree(prims);
     (void)hipFree(nodes);
     return std::string("device tree build: ") + hipGetErrorString(e);
+  }
+  if (std::getenv("PTK_LBVH_REPORT")) {  // diagnostic: leaves by size and by level of the finished tree
+    std::vector<NodePair> h(n_nodes);
+    if (hipMemcpy(h.data(), nodes, (size_t)n_nodes * sizeof(NodePair), hipMemcpyDeviceToHost) == hipSuccess) {
+      unsigned long long by_size[9] = {0}, by_level[kMaxTreeDepth + 2] = {0}, prims_by_level[kMaxTreeDepth + 2] = {0};
+      std::vector<std::pair<int32_t, int>> todo{{0, 1}};
+      while (!todo.empty()) {
+        auto [node, level] = todo.back();
+        todo.pop_back();
+        for (int32_t link : {h[node].child0, h[node].child1}) {
+          if (link >= 0) { todo.emplace_back(link, level + 1); continue; }
+          const uint32_t count = ((~(uint32_t)link) & 7u) + 1u;
+          by_size[count]++;
+          by_level[level < kMaxTreeDepth + 1 ? level : kMaxTreeDepth + 1]++;
+          prims_by_level[level < kMaxTreeDepth + 1 ? level : kMaxTreeDepth + 1] += count;
+        }
+      }
+      fprintf(stderr, "[ptk lbvh] %u nodes; leaves of 1..8 primitives:", n_nodes);
+      for (int k = 1; k <= 8; k++) fprintf(stderr, " %llu", by_size[k]);
+      fprintf(stderr, "\n[ptk lbvh] leaves (primitives) by level:");
+      for (int l = 1; l <= kMaxTreeDepth + 1; l++) if (by_level[l]) fprintf(stderr, " %d:%llu(%llu)", l, by_level[l], prims_by_level[l]);
+      fprintf(stderr, "\n");
+    }
   }
   out.nodes = nodes;
   out.prims = prims;

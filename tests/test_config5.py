@@ -43,7 +43,7 @@ def test_million_triangle_scene_hits_match_the_oracle(gpu_ctx, big_scene, big_or
     sd = big_scene
     b = GpuBackend(gpu_ctx, sd, builder)
     info = b.info()
-    assert info["n_prims"] == 1310720 + 12 and info["max_depth"] <= 25 and info["max_leaf"] <= 4
+    assert info["n_prims"] == 1310720 + 12 and info["max_depth"] <= 32 and info["max_leaf"] <= 4
     assert info["builder"] == (1 if builder == "device" else 0)
     rays, ref, sec = big_rays
     got, cgot = b.intersect(rays)

@@ -12,7 +12,7 @@ from tests.backends import GpuBackend, scene
 
 pytestmark = pytest.mark.gpu
 
-MAX_TREE_DEPTH = 25  # ptk_layout.h: kStackDepth - 2
+MAX_TREE_DEPTH = 32  # ptk_layout.h: kStackDepth - 2
 
 
 def _f32_rays(rays):

@@ -58,6 +58,11 @@ constexpr float kTraversalCost = 1.0f;
 #define PTK_SAH_INTERSECT_COST 1.2f
 #endif
 constexpr float kIntersectCost = PTK_SAH_INTERSECT_COST;
+// Largest leaf the surface-area heuristic may choose (the depth guard's median splits can still leave kMaxLeafSize).
+#ifndef PTK_SAH_LEAF_MAX
+#define PTK_SAH_LEAF_MAX kMaxLeafSize
+#endif
+constexpr int kSahLeafMax = PTK_SAH_LEAF_MAX;
 
 // Binned surface-area-heuristic builder.  Subtrees are independent, so the two sides of a large
 // split are built by different threads; which thread builds what does not influence the tree (every
@@ -188,7 +193,7 @@ struct Builder {
         }
       }
     }
-    bool must_split = count > kMaxLeafSize;
+    bool must_split = count > kSahLeafMax;
     bool want_split = best_axis >= 0 && best_cost < kIntersectCost * (float)count;
     if (!must_split && (!want_split || depth + 1 > kMaxTreeDepth)) {
       raise(max_leaf, count);
@@ -266,7 +271,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
     h0 = (h0 ^ w) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
     h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
   };
-  mix(((uint64_t)kMaxLeafSize << 32) | (uint64_t)kMaxTreeDepth);
+  mix(((uint64_t)kMaxLeafSize << 32) | ((uint64_t)kSahLeafMax << 16) | (uint64_t)kMaxTreeDepth);
   mix(((uint64_t)kBins << 32) | 4u /* builder revision: change when the builder's decisions change */);
   uint32_t ic, tc;
   std::memcpy(&ic, &kIntersectCost, 4); std::memcpy(&tc, &kTraversalCost, 4);
@@ -372,7 +377,7 @@ SceneView HostScene::host_view() const
   v.shade = shade.data();
   v.materials = materials.data();
   v.lights = lights.data();
-  v.textures = textures.data();
+  v.textures = textures.data() + kGammaLutRecords;
   v.texels = texels.data();
   v.n_prims = n_prims;
   v.n_triangles = n_triangles;
@@ -405,6 +410,11 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   out.n_triangles = d.n_triangles;
 
   // --- textures ------------------------------------------------------------
+  out.textures.resize(kGammaLutRecords);  // the gamma table goes first (ptk_layout.h)
+  {
+    float* lut = reinterpret_cast<float*>(out.textures.data());
+    for (int i = 0; i < 256; i++) lut[i] = (float)std::pow((double)i / 255.0, 2.2);
+  }
   for (int i = 0; i < d.n_textures; i++) {
     const ptk_texture& t = d.textures[i];
     if (t.width <= 0 || t.height <= 0 || !t.rgb) return "invalid texture";
@@ -413,11 +423,12 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     r.width = t.width; r.height = t.height;
     size_t bytes = (size_t)t.width * (size_t)t.height * 3;
     out.texels.insert(out.texels.end(), t.rgb, t.rgb + bytes);
-    out.texels.push_back(0);  // the kernels fetch a texel as one 4-byte word: a byte beyond the last texel must exist
+    out.texels.insert(out.texels.end(), 8, 0);  // the kernels fetch two texels as one 8-byte word: bytes beyond the last texel must exist
     while (out.texels.size() % 16) out.texels.push_back(0);
+    if (out.texels.size() > 0xfffffff0ull) return "textures exceed 4 GiB (byte offsets into the texel pool are 32 bits)";
     out.textures.push_back(r);
   }
-  if (out.textures.empty()) { TextureRec r; r.offset = 0; r.width = r.height = 0; out.textures.push_back(r); }
+  if (out.textures.size() == (size_t)kGammaLutRecords) { TextureRec r; r.offset = 0; r.width = r.height = 0; out.textures.push_back(r); }
   if (out.texels.empty()) out.texels.resize(16, 0);
 
   // --- materials -------------------------------------------------------------

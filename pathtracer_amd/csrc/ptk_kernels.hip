@@ -1083,7 +1083,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
   v.shade = (const ShadeRec*)ctx->d_shade;
   v.materials = (const MaterialRec*)ctx->d_materials;
   v.lights = (const LightRec*)ctx->d_lights;
-  v.textures = (const TextureRec*)ctx->d_textures;
+  v.textures = (const TextureRec*)ctx->d_textures + kGammaLutRecords;  // behind the gamma table
   v.texels = (const uint8_t*)ctx->d_texels;
   ctx->view = v;
   ctx->texel_bytes = h.texels.size();

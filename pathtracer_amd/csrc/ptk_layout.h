@@ -192,6 +192,12 @@ struct alignas(16) TextureRec {
   int32_t width, height;
 };
 
+// The texture records are preceded, in the same array, by a table of pow(i / 255, 2.2) for i = 0 .. 255 (what a
+// texel's byte becomes before it is used as a colour): 256 floats = kGammaLutRecords records' worth.  SceneView::textures
+// points at the first real record, the table lies just below it - no further kernel argument for it.
+constexpr int kGammaLutRecords = 256 * (int)sizeof(float) / (int)sizeof(TextureRec);
+static_assert(kGammaLutRecords * sizeof(TextureRec) == 256 * sizeof(float), "the table fills whole records");
+
 // Everything a kernel needs to know about the scene; passed by value as a kernel argument.
 struct SceneView {
   const NodePair* nodes;
@@ -208,6 +214,8 @@ struct SceneView {
   int32_t background_is_color; // all components >= 0 (src/scene.cpp:39)
   float background_color[3];
 };
+
+PTK_HD const float* gamma_lut(const SceneView& sc) { return reinterpret_cast<const float*>(sc.textures) - 256; }
 
 struct CameraView {  // src/camera.h:21-26 after compute()
   int32_t width, height;

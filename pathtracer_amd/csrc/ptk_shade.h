@@ -103,37 +103,28 @@ struct Texel {
   int r, g, b;
 };
 
-// Image::pixel, src/image.cpp:40-48: out of range gives INVALID_COLOR, which as a u8vec3 is (1,0,1)
-PTK_HD Texel texel(const SceneView& sc, const TextureRec& t, int x, int y)
-{
-  Texel p = {1, 0, 1};
-  if (x < 0 || x >= t.width || y < 0 || y >= t.height) return p;
-  const uint8_t* q = sc.texels + t.offset + ((size_t)y * (size_t)t.width + (size_t)x) * 3;
-#if defined(__HIP_DEVICE_COMPILE__)
-  // one 4-byte fetch instead of three 1-byte ones (the texel pool ends in padding, so the fourth byte exists;
-  // global memory takes unaligned 4-byte loads)
-  struct __attribute__((packed)) Word { uint32_t v; };
-  const uint32_t w = reinterpret_cast<const Word*>(q)->v;
-  p.r = (int)(w & 0xffu); p.g = (int)((w >> 8) & 0xffu); p.b = (int)((w >> 16) & 0xffu);
-#else
-  p.r = q[0]; p.g = q[1]; p.b = q[2];
-#endif
-  return p;
-}
-
 // glm::mix on u8vec3 converts the blended value back to uint8 (truncation) at every lerp, src/image.cpp:78;
 // out-of-range blends (negative fractions from texture coordinates below 0) keep their low byte
 PTK_HD Texel mix_u8(Texel a, Texel b, float t)
 {
+  // One rounded product and one fused multiply-add, spelled out: the truncation below turns a last-bit difference
+  // into a whole step of the texel's value, so how the sum is contracted must not be left to each instantiation of
+  // the kernel template.
   Texel r;
-  r.r = ((int)((float)a.r * (1.0f - t) + (float)b.r * t)) & 255;
-  r.g = ((int)((float)a.g * (1.0f - t) + (float)b.g * t)) & 255;
-  r.b = ((int)((float)a.b * (1.0f - t) + (float)b.b * t)) & 255;
+  const float s = 1.0f - t;
+  r.r = ((int)fmaf((float)b.r, t, (float)a.r * s)) & 255;
+  r.g = ((int)fmaf((float)b.g, t, (float)a.g * s)) & 255;
+  r.b = ((int)fmaf((float)b.b, t, (float)a.b * s)) & 255;
   return r;
 }
 
-// Image::sample, src/image.cpp:62-85
-PTK_HD v3 sample_texture(const SceneView& sc, int tex, float u, float v)
+// Image::sample, src/image.cpp:62-85, with Image::pixel, src/image.cpp:40-48 (a tap outside the image gives
+// INVALID_COLOR, which as a u8vec3 is (1,0,1)).  Straight-line: the two taps of a row are six consecutive bytes,
+// fetched as ONE 8-byte word from a clamped position (the texel pool ends in padding, global memory takes
+// unaligned loads, and byte offsets into the pool fit 32 bits: build_host_scene checks), and which taps lie outside
+// the image is settled by selects afterwards.  Both fetches are in flight together; taken one tap at a time behind
+// its own bounds check, the four fetches of a sample each waited for the one before.
+PTK_HD Texel sample_texture(const SceneView& sc, int tex, float u, float v)
 {
   const TextureRec t = sc.textures[tex];
   float x = u * (float)(t.width - 1);
@@ -142,10 +133,41 @@ PTK_HD v3 sample_texture(const SceneView& sc, int tex, float u, float v)
   int x0 = (x > -2.0e9f && x < 2.0e9f) ? (int)x : -0x40000000;
   int y0 = (y > -2.0e9f && y < 2.0e9f) ? (int)y : -0x40000000;
   float fx = x - (float)x0, fy = y - (float)y0;
-  Texel tl = texel(sc, t, x0, y0), tr = texel(sc, t, x0 + 1, y0);
-  Texel bl = texel(sc, t, x0, y0 + 1), br = texel(sc, t, x0 + 1, y0 + 1);
-  Texel p = mix_u8(mix_u8(tl, tr, fx), mix_u8(bl, br, fx), fy);
-  return V3((float)p.r / 255.0f, (float)p.g / 255.0f, (float)p.b / 255.0f);
+  const bool x_in0 = (uint32_t)x0 < (uint32_t)t.width, x_in1 = (uint32_t)(x0 + 1) < (uint32_t)t.width;
+  const bool y_in0 = (uint32_t)y0 < (uint32_t)t.height, y_in1 = (uint32_t)(y0 + 1) < (uint32_t)t.height;
+  const bool at_left_edge = x0 < 0;  // x0 == -1: the right tap is the texel the clamped fetch starts at
+  auto clampi = [](int i, int last) { return i < 0 ? 0 : (i > last ? last : i); };
+  const int xb = clampi(x0, t.width - 1), yb0 = clampi(y0, t.height - 1), yb1 = clampi(y0 + 1, t.height - 1);
+  const uint32_t base = (uint32_t)t.offset + (uint32_t)xb * 3u;
+  const uint32_t row_bytes = (uint32_t)t.width * 3u;
+  const uint8_t* q0 = sc.texels + (base + (uint32_t)yb0 * row_bytes);
+  const uint8_t* q1 = sc.texels + (base + (uint32_t)yb1 * row_bytes);
+  Texel a0, a1, b0, b1;  // row y0: texel at xb and its right neighbour; row y0 + 1 likewise
+#if defined(__HIP_DEVICE_COMPILE__)
+  struct __attribute__((packed)) Pair { uint32_t lo, hi; };
+  const Pair w0 = *reinterpret_cast<const Pair*>(q0), w1 = *reinterpret_cast<const Pair*>(q1);
+  a0.r = (int)(w0.lo & 0xffu); a0.g = (int)((w0.lo >> 8) & 0xffu); a0.b = (int)((w0.lo >> 16) & 0xffu);
+  a1.r = (int)(w0.lo >> 24); a1.g = (int)(w0.hi & 0xffu); a1.b = (int)((w0.hi >> 8) & 0xffu);
+  b0.r = (int)(w1.lo & 0xffu); b0.g = (int)((w1.lo >> 8) & 0xffu); b0.b = (int)((w1.lo >> 16) & 0xffu);
+  b1.r = (int)(w1.lo >> 24); b1.g = (int)(w1.hi & 0xffu); b1.b = (int)((w1.hi >> 8) & 0xffu);
+#else
+  a0.r = q0[0]; a0.g = q0[1]; a0.b = q0[2]; a1.r = q0[3]; a1.g = q0[4]; a1.b = q0[5];
+  b0.r = q1[0]; b0.g = q1[1]; b0.b = q1[2]; b1.r = q1[3]; b1.g = q1[4]; b1.b = q1[5];
+#endif
+  const Texel outside = {1, 0, 1};
+  auto pick = [&](bool inside, const Texel& p) { Texel r = outside; if (inside) r = p; return r; };
+  const Texel tl = pick(x_in0 && y_in0, a0), tr = pick(x_in1 && y_in0, at_left_edge ? a0 : a1);
+  const Texel bl = pick(x_in0 && y_in1, b0), br = pick(x_in1 && y_in1, at_left_edge ? b0 : b1);
+  return mix_u8(mix_u8(tl, tr, fx), mix_u8(bl, br, fx), fy);
+}
+
+// pow(texel / 255, 2.2), which is what both users of a texture sample compute from it (src/geometry.cpp:18-26,
+// src/scene.cpp:33-45): a table of the 256 possible values (gamma_lut in ptk_layout.h) instead of a logarithm and
+// an exponential per channel.
+PTK_HD v3 texel_to_linear(const SceneView& sc, Texel p)
+{
+  const float* lut = gamma_lut(sc);
+  return V3(lut[p.r], lut[p.g], lut[p.b]);
 }
 
 // Scene::sample_background, src/scene.cpp:21-45; equirectangular, src/util.h:142-149
@@ -154,7 +176,7 @@ PTK_HD v3 background(const SceneView& sc, v3 dir)
   if (sc.background_texture >= 0) {
     float u = atan2f(dir.z, dir.x) * 0.1591f + 0.5f;
     float v = asinf(dir.y) * 0.3183f + 0.5f;
-    return pow3(sample_texture(sc, sc.background_texture, u, v), 2.2f);
+    return texel_to_linear(sc, sample_texture(sc, sc.background_texture, u, v));
   }
   if (sc.background_is_color) return ld3(sc.background_color);
   float a = 0.5f * (dir.y + 1.0f);
@@ -165,7 +187,9 @@ PTK_HD v3 background(const SceneView& sc, v3 dir)
 template <class M>
 PTK_HD v3 surface_albedo(const SceneView& sc, const M& m, const Surface& s)
 {
-  if (m.texture >= 0) return pow3(sample_texture(sc, m.texture, s.uv[0], s.uv[1]), 2.2f);
+#ifndef PTK_WHATIF_NO_TEXTURE  // (what-if build for weighing the texture path: wrong colours, same paths)
+  if (m.texture >= 0) return texel_to_linear(sc, sample_texture(sc, m.texture, s.uv[0], s.uv[1]));
+#endif
   return ld3(m.albedo);
 }
 

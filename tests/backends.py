@@ -84,6 +84,8 @@ def scene(name: str):
         return scenes.cornell_box(64, 64)
     if name == "cornell_pinhole":
         return scenes.cornell_box(64, 64, aperture=0.0, focus_distance=0.0)
+    if name == "cornell_plain_floor":
+        return scenes.cornell_box(64, 64, textured_floor=False)
     if name == "mesh":  # 5 120-triangle mesh + box + both spheres
         s = scenes.cornell_with_mesh(4, 64, 64)
         scenes.add_json_spheres(s)

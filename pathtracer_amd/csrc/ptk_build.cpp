@@ -443,6 +443,13 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     r.roughness = (float)m.roughness;
     r.metallic = (float)m.metallic;
     for (int k = 0; k < 3; k++) { r.albedo[k] = (float)m.albedo[k]; r.emission[k] = (float)m.emission[k]; }
+    if (m.texture >= 0) {
+      // a textured material's colour comes from the texture alone (Intersection::albedo, src/geometry.cpp:18-26): the
+      // three words hold the texture's own record instead, which spares every textured hit a dependent fetch of it
+      const TextureRec& t = out.textures[(size_t)kGammaLutRecords + (size_t)m.texture];
+      const uint32_t words[3] = {(uint32_t)t.offset, (uint32_t)t.width, (uint32_t)t.height};
+      std::memcpy(r.albedo, words, sizeof words);
+    }
     if (m.emission[0] > 0.0 || m.emission[1] > 0.0 || m.emission[2] > 0.0) r.flags |= kMatLight;
     bool spec = (m.type & PTK_DIELECTRIC) || (m.type & PTK_MIRROR) ||
                 (((m.type & PTK_SPECULAR) || (m.type & PTK_MICROFACET)) && m.roughness < 1e-5);

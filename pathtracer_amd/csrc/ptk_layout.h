@@ -167,7 +167,7 @@ struct alignas(16) MaterialRec {
   int32_t texture; // -1 = none
   uint32_t flags;
   float ior;
-  float albedo[3];
+  float albedo[3];  // texture >= 0: the bits of the texture's byte offset in the texel pool, its width and its height
   float roughness;
   float emission[3];
   float metallic;

@@ -44,7 +44,12 @@ PTK_HD Rng rng_init(uint32_t seed, uint32_t pixel, uint32_t sample)
 // uniform in [0,1), 24 bits
 PTK_HD float rnd(Rng& r)
 {
+#ifdef PTK_WHATIF_CHEAP_RNG  // (what-if build for weighing the generator: one multiply instead of two; other numbers, similar paths)
+  uint32_t x = (r.c ^ r.k1) * 0x21f0aaadu;
+  x ^= x >> 15;
+#else
   uint32_t x = mix32(r.c ^ r.k1);
+#endif
   r.c += 0x9E3779B9u;
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
@@ -124,9 +129,17 @@ PTK_HD Texel mix_u8(Texel a, Texel b, float t)
 // unaligned loads, and byte offsets into the pool fit 32 bits: build_host_scene checks), and which taps lie outside
 // the image is settled by selects afterwards.  Both fetches are in flight together; taken one tap at a time behind
 // its own bounds check, the four fetches of a sample each waited for the one before.
-PTK_HD Texel sample_texture(const SceneView& sc, int tex, float u, float v)
+struct TextureView {
+  uint32_t offset;  // of the first texel, in bytes from the start of the texel pool
+  int32_t width, height;
+};
+PTK_HD TextureView texture_view(const SceneView& sc, int tex)
 {
-  const TextureRec t = sc.textures[tex];
+  const TextureRec r = sc.textures[tex];
+  return TextureView{(uint32_t)r.offset, r.width, r.height};
+}
+PTK_HD Texel sample_texture(const SceneView& sc, const TextureView& t, float u, float v)
+{
   float x = u * (float)(t.width - 1);
   float y = v * (float)(t.height - 1);
   // int(x) truncates toward zero; NaN and out-of-range coordinates must land outside the image
@@ -138,7 +151,7 @@ PTK_HD Texel sample_texture(const SceneView& sc, int tex, float u, float v)
   const bool at_left_edge = x0 < 0;  // x0 == -1: the right tap is the texel the clamped fetch starts at
   auto clampi = [](int i, int last) { return i < 0 ? 0 : (i > last ? last : i); };
   const int xb = clampi(x0, t.width - 1), yb0 = clampi(y0, t.height - 1), yb1 = clampi(y0 + 1, t.height - 1);
-  const uint32_t base = (uint32_t)t.offset + (uint32_t)xb * 3u;
+  const uint32_t base = t.offset + (uint32_t)xb * 3u;
   const uint32_t row_bytes = (uint32_t)t.width * 3u;
   const uint8_t* q0 = sc.texels + (base + (uint32_t)yb0 * row_bytes);
   const uint8_t* q1 = sc.texels + (base + (uint32_t)yb1 * row_bytes);
@@ -176,7 +189,7 @@ PTK_HD v3 background(const SceneView& sc, v3 dir)
   if (sc.background_texture >= 0) {
     float u = atan2f(dir.z, dir.x) * 0.1591f + 0.5f;
     float v = asinf(dir.y) * 0.3183f + 0.5f;
-    return texel_to_linear(sc, sample_texture(sc, sc.background_texture, u, v));
+    return texel_to_linear(sc, sample_texture(sc, texture_view(sc, sc.background_texture), u, v));
   }
   if (sc.background_is_color) return ld3(sc.background_color);
   float a = 0.5f * (dir.y + 1.0f);
@@ -188,7 +201,10 @@ template <class M>
 PTK_HD v3 surface_albedo(const SceneView& sc, const M& m, const Surface& s)
 {
 #ifndef PTK_WHATIF_NO_TEXTURE  // (what-if build for weighing the texture path: wrong colours, same paths)
-  if (m.texture >= 0) return texel_to_linear(sc, sample_texture(sc, m.texture, s.uv[0], s.uv[1]));
+  if (m.texture >= 0) {  // the material record carries its texture's record in place of a colour (MaterialRec::albedo)
+    const TextureView t = {as_uint(m.albedo[0]), (int32_t)as_uint(m.albedo[1]), (int32_t)as_uint(m.albedo[2])};
+    return texel_to_linear(sc, sample_texture(sc, t, s.uv[0], s.uv[1]));
+  }
 #endif
   return ld3(m.albedo);
 }
@@ -476,6 +492,12 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
     normal = ((s.point + to_light * t) - ld3(light.p0)) * (1.0f / light.radius);
     if (dot(to_light, normal) > 0.0f) normal = -normal;
   }
+#ifdef PTK_WHATIF_NO_NEE_MATH  // (what-if build for weighing the light term's arithmetic: wrong radiance, same rays)
+  pending_out = scale;
+  light_id_out = light.id; to_light_out = to_light; distance_out = distance;
+  t_stop_out = light.kind == kTriangle ? distance * 0.999f - 1e-3f : -1.0f;
+  return true;
+#endif
   float light_cos = fmaxf(dot(normal, -to_light), 0.0f);
   float weight = light.area * light_cos * frcp(distance * distance);
   // Only the microfacet model looks at the directions; every other BxDF::eval is a constant

@@ -9,6 +9,17 @@
  * ptk_last_error().  Nothing throws or exits across this boundary (the
  * reference calls exit(1) / assert: src/scene.cpp:107, src/scene.cpp:51).
  *
+ * Interfaces of the reference that have NO entry point here, because the reference
+ * only ever calls them from inside its render loop and that loop now runs on the GPU
+ * as a whole: Camera::get_ray (src/camera.h:15), Scene::sample_background and
+ * Scene::random_light (src/scene.h:24-27), Image::sample / Image::pixel (src/image.h),
+ * BxDF::sample / eval / pdf (src/material.h:38-65), Renderer::trace_ray /
+ * sample_lights (src/renderer.h), Primitive::intersect / sample_point
+ * (src/geometry.h), BVH and AABB as classes.  Their work is done by device functions
+ * of the render kernel; ptk_intersect_batch is the one query a host caller can pose
+ * by itself (Scene::find_intersection).  The C++ mirror above this header
+ * (pathtracer_amd/host/) leaves the same methods out.
+ *
  * A context is bound to one GPU and is not thread-safe; use one context per
  * device (one process per GPU in multi-GPU runs).  Host input arrays are
  * copied during the call; device memory belongs to the context until

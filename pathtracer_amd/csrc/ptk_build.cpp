@@ -253,7 +253,6 @@ inline float f_up(double x)
   return ((double)f < x) ? std::nextafter(f, std::numeric_limits<float>::infinity()) : f;
 }
 
-int32_t leaf_code(int first, int count) { return (int32_t) ~(((uint32_t)first << 3) | (uint32_t)(count - 1)); }
 
 void set_child_box(NodePair& n, int which, const Box& b, const BoxGrid& g) { set_child_box(n, which, b.lo, b.hi, g); }
 
@@ -264,7 +263,7 @@ struct CacheKey {
 
 // Two independent multiply-xorshift hashes over the boxes (the only input of the tree) and the limits
 // that shape it.
-CacheKey hash_boxes(const std::vector<Box>& boxes)
+CacheKey hash_boxes(const std::vector<Box>& boxes, int32_t n_triangles)
 {
   uint64_t h0 = 0x243F6A8885A308D3ull ^ (uint64_t)boxes.size(), h1 = 0x13198A2E03707344ull + (uint64_t)boxes.size();
   auto mix = [&](uint64_t w) {
@@ -273,6 +272,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
   };
   mix(((uint64_t)kMaxLeafSize << 32) | ((uint64_t)kSahLeafMax << 16) | (uint64_t)kMaxTreeDepth);
   mix(((uint64_t)kBins << 32) | 4u /* builder revision: change when the builder's decisions change */);
+  mix((uint64_t)(uint32_t)n_triangles);  // which primitives are spheres: leaf links say whether a leaf holds one
   uint32_t ic, tc;
   std::memcpy(&ic, &kIntersectCost, 4); std::memcpy(&tc, &kTraversalCost, 4);
   mix(((uint64_t)ic << 32) | tc);
@@ -283,7 +283,7 @@ CacheKey hash_boxes(const std::vector<Box>& boxes)
 }
 
 struct CacheHeader {
-  char magic[8];  // "PTKBVH5\0"
+  char magic[8];  // "PTKBVH6\0"
   uint64_t key_a, key_b;
   int32_t n_prims, n_nodes, max_depth, max_leaf;
 };
@@ -315,7 +315,7 @@ bool tree_is_valid(const std::vector<NodePair>& nodes, const std::vector<uint32_
     visited[t.node] = 1;
     for (int32_t link : {nodes[t.node].child0, nodes[t.node].child1}) {
       if (link >= 0) { stack.push_back({link, t.depth + 1}); continue; }
-      uint32_t leaf = ~(uint32_t)link, first = leaf >> 3, count = (leaf & 7u) + 1u;
+      uint32_t first = leaf_first(link), count = leaf_count(link);
       if ((int32_t)count > max_leaf || (uint64_t)first + count > (uint64_t)n_prims) return false;
       for (uint32_t i = first; i < first + count; i++) {
         if (covered[i]) return false;
@@ -333,7 +333,7 @@ bool cache_load(const std::string& path, CacheKey key, int32_t n_prims, std::vec
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   CacheHeader h;
-  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH5", 8) == 0 && h.key_a == key.a &&
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "PTKBVH6", 8) == 0 && h.key_a == key.a &&
             h.key_b == key.b && h.n_prims == n_prims && h.n_nodes >= 1 && h.n_nodes <= n_prims + 1;
   if (ok) {
     nodes.resize((size_t)h.n_nodes);
@@ -356,7 +356,7 @@ void cache_store(const std::string& path, CacheKey key, const std::vector<NodePa
   if (!f) return;
   CacheHeader h;
   std::memset(&h, 0, sizeof h);
-  std::memcpy(h.magic, "PTKBVH5", 8);
+  std::memcpy(h.magic, "PTKBVH6", 8);
   h.key_a = key.a; h.key_b = key.b;
   h.n_prims = (int32_t)order.size(); h.n_nodes = (int32_t)nodes.size();
   h.max_depth = max_depth; h.max_leaf = max_leaf;
@@ -590,7 +590,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     std::memset(&e, 0, sizeof e);
     // both children: the one all-zero primitive record (a degenerate triangle that no ray hits)
     set_child_box(e, 0, scene_box, out.grid); set_child_box(e, 1, scene_box, out.grid);
-    e.child0 = e.child1 = leaf_code(0, 1);
+    e.child0 = e.child1 = leaf_code(0u, 1u, false);
     out.nodes.push_back(e);
     out.prims.assign(1, by_id[0]);
     return std::string();
@@ -629,7 +629,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
   std::string cache_file;
   CacheKey cache_key{0, 0};
   if (cache_dir && *cache_dir && n >= kDeviceBuildMin) {
-    cache_key = hash_boxes(boxes);
+    cache_key = hash_boxes(boxes, out.n_triangles);
     cache_file = cache_path(cache_dir, cache_key);
     std::vector<uint32_t> order;
     if (cache_load(cache_file, cache_key, n, out.nodes, order, out.max_depth, out.max_leaf)) {
@@ -675,9 +675,14 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
       }
     }
   }
+  auto holds_sphere = [&](int32_t first, int32_t count) {
+    for (int32_t i = first; i < first + count; i++)
+      if (as_uint(out.prims[(size_t)i].c.y) & kPrimSphereBit) return true;
+    return false;
+  };
   auto child_code = [&](int32_t b, std::vector<Item>& todo) -> int32_t {
     const BuildNode& bn = bld.nodes[b];
-    if (bn.left < 0) return leaf_code(leaf_first[b], bn.count);
+    if (bn.left < 0) return leaf_code((uint32_t)leaf_first[b], (uint32_t)bn.count, holds_sphere(leaf_first[b], bn.count));
     int32_t idx = (int32_t)out.nodes.size();
     out.nodes.emplace_back();
     std::memset(&out.nodes.back(), 0, sizeof(NodePair));
@@ -692,7 +697,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
     // tested twice, and the second time none of them is strictly closer
     set_child_box(e, 0, bld.nodes[0].box, out.grid);
     set_child_box(e, 1, bld.nodes[0].box, out.grid);
-    e.child0 = e.child1 = leaf_code(0, bld.nodes[0].count);
+    e.child0 = e.child1 = leaf_code(0u, (uint32_t)bld.nodes[0].count, holds_sphere(0, bld.nodes[0].count));
     out.nodes.push_back(e);
     return std::string();
   }

@@ -1037,7 +1037,7 @@ static int finish_upload(ptk_ctx* ctx, int32_t builder, bool keep_host = false)
     if ((rc = upload(ctx, &d_boxes, h.prim_boxes))) { if (d_boxes) (void)hipFree(d_boxes); return rc; }
     if ((rc = upload(ctx, &d_by_id, h.prims))) { (void)hipFree(d_boxes); if (d_by_id) (void)hipFree(d_by_id); return rc; }
     DeviceTree tree;
-    std::string why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.centroid_lo,
+    std::string why = build_device_tree(ctx->stream, (const float*)d_boxes, (const PrimRec*)d_by_id, h.n_prims, h.n_triangles, h.centroid_lo,
                                         h.centroid_hi, h.max_diagonal, h.grid, tree);
     (void)hipFree(d_boxes);
     (void)hipFree(d_by_id);

@@ -24,10 +24,10 @@ struct DeviceTree {
 };
 
 // d_boxes: 6 floats (lo.xyz, hi.xyz) per primitive, d_prims_by_id: the primitives' records in id order,
-// both in device memory; n >= 8.  grid: the scene's box grid (NodePair).  centroid_lo/hi bound the box centres, max_diagonal is the longest box
+// both in device memory; n >= 8; primitives n_triangles .. n - 1 are spheres (leaves that hold one are marked).  grid: the scene's box grid (NodePair).  centroid_lo/hi bound the box centres, max_diagonal is the longest box
 // diagonal.  Work is enqueued on `stream` and the call returns after it has finished.
 // Returns an empty string on success, otherwise what failed.
-std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n,
+std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n, int32_t n_triangles,
                               const float centroid_lo[3], const float centroid_hi[3], float max_diagonal,
                               const BoxGrid& grid, DeviceTree& out);
 

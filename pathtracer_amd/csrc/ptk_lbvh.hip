@@ -81,7 +81,8 @@ __device__ inline int median_levels(uint32_t n)
   return l;
 }
 
-__device__ inline int32_t leaf_link(uint32_t first, uint32_t count) { return (int32_t) ~((first << 3) | (count - 1u)); }
+// (whether a leaf holds a sphere is settled by the fitting pass, which looks at its primitives anyway)
+__device__ inline int32_t leaf_link(uint32_t first, uint32_t count, bool spheres = false) { return leaf_code(first, count, spheres); }
 
 // Nodes [begin, end) are the inner nodes at `depth`; each holds a range of at least two primitives.
 // Ranges of at most this many primitives are not split where a key bit flips but where the surface-area heuristic is
@@ -202,17 +203,20 @@ constexpr uint32_t kMergedLeafMax = PTK_LBVH_MERGED_LEAF_MAX;
 // kMaxLeafSize primitives together, is replaced by one leaf when testing all of them costs no more
 // (surface-area heuristic) than visiting the node first; `link` is updated then and the node is left unused.
 __device__ inline QBox child_box(int32_t& link, const float* __restrict__ boxes, const uint32_t* __restrict__ order,
-                                 const NodePair* nodes, const BoxGrid& g)
+                                 const NodePair* nodes, const BoxGrid& g, uint32_t n_triangles)
 {
   QBox r;
   if (link < 0) {
-    const uint32_t leaf = ~(uint32_t)link;
-    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+    const uint32_t first = leaf_first(link), count = leaf_count(link);
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    bool spheres = false;
     for (uint32_t j = 0; j < count; j++) {
-      const float* b = boxes + 6 * (size_t)order[first + j];
+      const uint32_t id = order[first + j];
+      spheres = spheres || id >= n_triangles;  // primitive ids: triangles first
+      const float* b = boxes + 6 * (size_t)id;
       for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); }
     }
+    link = leaf_link(first, count, spheres);
     r.x = grid_word(lo[0], hi[0], g.origin[0], g.scale[0]);
     r.y = grid_word(lo[1], hi[1], g.origin[1], g.scale[1]);
     r.z = grid_word(lo[2], hi[2], g.origin[2], g.scale[2]);
@@ -221,14 +225,13 @@ __device__ inline QBox child_box(int32_t& link, const float* __restrict__ boxes,
     const QBox b0{c.x0, c.y0, c.z0}, b1{c.x1, c.y1, c.z1};
     r.x = q_union(b0.x, b1.x); r.y = q_union(b0.y, b1.y); r.z = q_union(b0.z, b1.z);
     if (c.child0 < 0 && c.child1 < 0) {
-      const uint32_t l0 = ~(uint32_t)c.child0, l1 = ~(uint32_t)c.child1;
-      const uint32_t n0 = (l0 & 7u) + 1u, n1 = (l1 & 7u) + 1u;
-      // one leaf needs one range: l1 has to start where l0 ends (always so unless regroup() moved a leaf here)
-      if (n0 + n1 <= kMergedLeafMax && (l1 >> 3) == (l0 >> 3) + n0) {
+      const uint32_t n0 = leaf_count(c.child0), n1 = leaf_count(c.child1);
+      // one leaf needs one range: the second has to start where the first ends (always so unless regroup() moved a leaf here)
+      if (n0 + n1 <= kMergedLeafMax && leaf_first(c.child1) == leaf_first(c.child0) + n0) {
         const float a = q_half_area(r, g);
         const float split = kTraversalCost * a + kIntersectCost * (q_half_area(b0, g) * (float)n0 + q_half_area(b1, g) * (float)n1);
         const float leaf = kIntersectCost * a * (float)(n0 + n1);
-        if (leaf <= kMergeBias * split) link = leaf_link(l0 >> 3, n0 + n1);
+        if (leaf <= kMergeBias * split) link = leaf_link(leaf_first(c.child0), n0 + n1, leaf_has_spheres(c.child0) || leaf_has_spheres(c.child1));
       }
     }
   }
@@ -276,7 +279,7 @@ __device__ inline void regroup(NodePair* nodes, int32_t l, int32_t r, uint32_t* 
 __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __restrict__ boxes,
                                                                 const uint32_t* __restrict__ order, NodePair* nodes,
                                                                 uint32_t begin, uint32_t end, uint32_t* __restrict__ live,
-                                                                uint32_t* __restrict__ subtree, BoxGrid g)
+                                                                uint32_t* __restrict__ subtree, BoxGrid g, uint32_t n_triangles)
 {
   uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= end) return;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __r
 #ifndef PTK_LBVH_NO_REGROUP
   if (c0 >= 0 && c1 >= 0) regroup(nodes, c0, c1, subtree, g);
 #endif
-  const QBox b0 = child_box(c0, boxes, order, nodes, g), b1 = child_box(c1, boxes, order, nodes, g);
+  const QBox b0 = child_box(c0, boxes, order, nodes, g, n_triangles), b1 = child_box(c1, boxes, order, nodes, g, n_triangles);
   nodes[i].child0 = c0;
   nodes[i].child1 = c1;
   // A node merged into a leaf has only leaves below it, so whatever an inner link still points at is in use.
@@ -353,7 +356,7 @@ inline unsigned blocks_for(uint32_t n) { return (n + kBuildBlock - 1) / kBuildBl
     if (e_ != hipSuccess) return std::string(#call) + ": " + hipGetErrorString(e_);      \
   } while (0)
 
-std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n,
+std::string build_device_tree(hipStream_t stream, const float* d_boxes, const PrimRec* d_prims_by_id, int32_t n, int32_t n_triangles,
                               const float centroid_lo[3], const float centroid_hi[3], float max_diagonal,
                               const BoxGrid& grid, DeviceTree& out)
 {
@@ -429,7 +432,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   LBVH_HIP(hipMemsetAsync(new_index, 0, sizeof(uint32_t), stream));                 // stays node 0
   for (size_t l = levels.size(); l-- > 0;) {
     fit_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
-        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree, grid);
+        d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree, grid, (uint32_t)n_triangles);
     LBVH_HIP(hipGetLastError());
   }
   for (size_t l = 0; l < levels.size(); l++) {
@@ -470,7 +473,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
         todo.pop_back();
         for (int32_t link : {h[node].child0, h[node].child1}) {
           if (link >= 0) { todo.emplace_back(link, level + 1); continue; }
-          const uint32_t count = ((~(uint32_t)link) & 7u) + 1u;
+          const uint32_t count = leaf_count(link);
           by_size[count]++;
           by_level[level < kMaxTreeDepth + 1 ? level : kMaxTreeDepth + 1]++;
           prims_by_level[level < kMaxTreeDepth + 1 ? level : kMaxTreeDepth + 1] += count;

@@ -336,8 +336,9 @@ PTK_HD void trav_inner(Traversal& tr, Stack& st, const SceneView& sc, Counters& 
   tr.node = none ? (int32_t)top : near;
 }
 
-// Test one primitive record against the lane's ray and keep it if it is the closest hit so far.
-template <bool STATS>
+// Test one primitive record against the lane's ray and keep it if it is the closest hit so far.  MAY_BE_SPHERE:
+// the record's kind is looked at; otherwise the caller knows it is a triangle (leaf_has_spheres).
+template <bool STATS, bool MAY_BE_SPHERE = true>
 PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
 {
   // id and kind share a word (PrimRec), which makes the record's third load 8 bytes instead of 12
@@ -348,7 +349,7 @@ PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
 #endif
   float t = 0.0f, u = 0.0f, v = 0.0f;
   bool ok;
-  if ((idw & kPrimSphereBit) == 0u) {
+  if (!MAY_BE_SPHERE || (idw & kPrimSphereBit) == 0u) {
     // a triangle the ray starts on is not a candidate (see the note at the top of this file)
     ok = hit_triangle(p, tr.o, tr.d, tr.hit.t, t, u, v) & (id != tr.skip_id);
   } else {
@@ -358,20 +359,17 @@ PTK_HD void trav_test_prim(Traversal& tr, const PrimRec& p, Counters& cnt)
   if (ok) { tr.hit.t = t; tr.hit.id = id; tr.hit.u = u; tr.hit.v = v; }
 }
 
-// Intersect the primitives of the leaf with code `node` (a negative child link).  Returns true when
-// the query is decided and needs no further traversal (see Traversal::t_stop).
-template <bool STATS, class Mem = GlobalMem>
-PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Counters& cnt, const Mem& mem = Mem())
+// The records of one leaf, one after the other.
+template <bool STATS, bool MAY_BE_SPHERE, class Mem>
+PTK_HD void trav_leaf_records(Traversal& tr, uint32_t first, uint32_t count, const SceneView& sc, Counters& cnt, const Mem& mem)
 {
-  const uint32_t leaf = ~(uint32_t)node;
-  const uint32_t count = (leaf & 7u) + 1u;
-  uint32_t off = (leaf >> 3) * (uint32_t)sizeof(PrimRec);
+  uint32_t off = first * (uint32_t)sizeof(PrimRec);
   if (!Mem::kPrefetch) {  // records in LDS arrive quickly: fetch, then test (+1 % on the Cornell box; from global memory -8 %)
     for (uint32_t i = 0; i < count; i++, off += (uint32_t)sizeof(PrimRec)) {
       const PrimRec p = mem.prim(sc, off);
-      trav_test_prim<STATS>(tr, p, cnt);
+      trav_test_prim<STATS, MAY_BE_SPHERE>(tr, p, cnt);
     }
-    return (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);
+    return;
   }
   // The next record is fetched while this one is tested.  Two records take turns (the loop is unrolled by two)
   // so that "next becomes current" is not ten register moves per primitive.
@@ -385,7 +383,7 @@ PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Co
 #endif
     const bool second = i + 1 < count;
     if (second) p1 = mem.prim(sc, off + (uint32_t)sizeof(PrimRec));
-    trav_test_prim<STATS>(tr, p0, cnt);
+    trav_test_prim<STATS, MAY_BE_SPHERE>(tr, p0, cnt);
     if (!second) break;
     const bool third = i + 2 < count;
     off += 2u * (uint32_t)sizeof(PrimRec);
@@ -396,9 +394,19 @@ PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Co
       if (__builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u)) == 0u) cnt.leaf_iterations++;
     }
 #endif
-    trav_test_prim<STATS>(tr, p1, cnt);
+    trav_test_prim<STATS, MAY_BE_SPHERE>(tr, p1, cnt);
     if (!third) break;
   }
+}
+
+// Intersect the primitives of the leaf with code `node` (a negative child link).  Returns true when
+// the query is decided and needs no further traversal (see Traversal::t_stop).
+template <bool STATS, class Mem = GlobalMem>
+PTK_HD bool trav_leaf_prims(Traversal& tr, int32_t node, const SceneView& sc, Counters& cnt, const Mem& mem = Mem())
+{
+  const uint32_t first = leaf_first(node), count = leaf_count(node);
+  if (leaf_has_spheres(node)) trav_leaf_records<STATS, true, Mem>(tr, first, count, sc, cnt, mem);  // (rare: skipped by whole waves)
+  else trav_leaf_records<STATS, false, Mem>(tr, first, count, sc, cnt, mem);
   return (tr.hit.t < tr.t_stop) & (tr.hit.id != tr.target);
 }
 

@@ -101,7 +101,7 @@ void hc_tree_check(void* h, int64_t* out)
       stack.push_back(c0); stack.push_back(c1);
       continue;
     }
-    const uint32_t leaf = ~(uint32_t)t.link, first = leaf >> 3, count = (leaf & 7u) + 1u;
+    const uint32_t first = leaf_first(t.link), count = leaf_count(t.link);
     for (uint32_t i = first; i < first + count && i < hs.prims.size(); i++) {
       const PrimRec& p = hs.prims[i];
       double lo[3], hi[3];

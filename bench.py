@@ -234,9 +234,10 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu, split
                 "bytes_frac_survey_note": "algorithmic bytes (32 per box test, 36 per primitive test, 48 per ray) over the HBM peak: "
                                           "what the lanes ask the caches for, most of it served by L1 / L2 / Infinity Cache; above 1 by "
                                           "construction on these scenes and NOT the reported fraction",
-                "note": "scene is cache resident: HBM-side traffic is a few percent of the HBM peak, so the fp32 vector rate is the "
-                        "bound reported; 'units' holds the hardware counters of the same launch from profiles/ (busy fractions of "
-                        "the vector ALU, the L1's address and data units)"}
+                "note": "the scene fits the L2s (32 MB) and the Infinity Cache: what leaves the L2s ('traffic': re-reads and register "
+                        "spills, 'hbm_frac' of the HBM peak if all of it reached HBM) is not the limit, so the fp32 vector rate is the "
+                        "bound reported; 'units' holds the hardware counters of the same launch from profiles/ (occupancy of "
+                        "the vector pipe, busy fractions of the L1's address and data units)"}
     if tr:
         roofline["units"] = {k: tr.get(k) for k in ("l1_hit_rate", "l2_hit_rate", "valu_lane_utilisation", "valu_fast_share",
                                                     "valu_pipe_occupancy_lower", "valu_pipe_occupancy_upper", "ta_busy", "td_busy",
@@ -244,13 +245,18 @@ def run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu, split
     if traffic is None:
         roofline["note"] = ("no hardware-counter pass is committed for this configuration (profiles/traffic.json): only the fp32 "
                             "vector-rate fraction is known")
-    if hbm_frac is not None and hbm_frac > valu_frac:
+    # Which fraction is reported: the memory one only for a scene that does not fit the eight 4 MB L2s together - for a
+    # smaller scene what leaves the L2s is re-reads that the 256 MB Infinity Cache serves and register spills, not HBM
+    # work, and the vector pipe is the unit that is full ('units').  Both fractions are in the line either way.
+    scene_bytes = info["node_bytes"] + info["prim_bytes"] + info["shading_bytes"]
+    roofline["scene_bytes"] = scene_bytes
+    if hbm_frac is not None and hbm_frac > valu_frac and scene_bytes > 8 * (4 << 20):
         roofline.update({"bound": "hbm", "achieved": traffic / kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac,
                          "note": "the scene (%.0f MB of nodes, primitive and shading records) does not fit the 4 MB L2 of an XCD: the "
                                  "measured bytes that leave the L2 per launch (FETCH_SIZE + WRITE_SIZE, profiles/traffic.json: an upper "
                                  "bound on HBM bytes, the 256 MB Infinity Cache serves part of them) over the launch time are the larger "
                                  "fraction; 'valu_frac' is the fp32 vector-rate fraction of the same launch"
-                                 % ((info["node_bytes"] + info["prim_bytes"] + info["shading_bytes"]) / 1e6),
+                                 % (scene_bytes / 1e6),
                          "valu_frac": valu_frac})
     out = {
         "value": queries / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / args.steps * 1e3,

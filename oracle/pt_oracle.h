@@ -12,6 +12,12 @@
  * reference outputs available are (1) the renders under doc/results/ and
  * (2) counters / the Cornell BVH topology recorded from a reference run
  * when the reference was surveyed; tests/ checks this file against both.
+ * Of the one published render of cornell_box.json the tests use the light, the
+ * walls, the textured floor, the field of view and the mirror and the glass
+ * sphere (mirror reflection, dielectric refraction, environment lookup), on
+ * pixels that do not depend on the bunny missing from the checkout.  Nothing
+ * the reference holds pins hit ids or distances, the microfacet model or
+ * sphere lights: for those this file stands on its line-by-line citations.
  *
  * Arithmetic follows the reference: double precision everywhere except the
  * places where the reference itself drops to float (shading frame, frame

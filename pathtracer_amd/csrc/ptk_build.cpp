@@ -511,6 +511,7 @@ std::string build_host_scene(const ptk_scene_desc& d, HostScene& out, bool with_
         l.n0[k] = (float)nr[k]; l.n1[k] = (float)nr[3 + k]; l.n2[k] = (float)nr[6 + k];
         l.emission[k] = out.materials[mat].emission[k];
       }
+      l.flat = (std::memcmp(l.n0, l.n1, sizeof l.n0) == 0 && std::memcmp(l.n0, l.n2, sizeof l.n0) == 0) ? 1u : 0u;
       sh.lights.push_back(l);
     }
   }

@@ -197,7 +197,8 @@ struct alignas(16) LightRec {
   float p0[3], p1[3], p2[3];  // triangle vertices; sphere: p0 = centre
   float emission[3];
   float n0[3], n1[3], n2[3];  // triangle vertex normals
-  float pad[3];
+  uint32_t flat;              // triangle: the three normals are equal (the interpolated one is then n0)
+  float pad[2];
 };
 static_assert(sizeof(LightRec) == 112, "LightRec is 112 bytes");
 

@@ -247,11 +247,20 @@ PTK_HD float schlick_reflectance(float cosine, float ri)
 
 // BxDF::sample, src/material.cpp:110-122.  Draw order: dielectric takes one uniform (the
 // reflect/refract choice), every other type two (direction).
+// The outgoing direction in the shading frame, worked out where a model reads it: the diffuse model, most of what a
+// wave shades, never does, and computed ahead of the branches it would be nine instructions for every shade step.
+struct LocalOut {
+  const Frame& fr;
+  v3 d;  // direction of the segment that arrived (the outgoing direction is -d)
+  PTK_HD v3 get() const { return to_local(fr, -d); }
+};
+
 template <class M>
-PTK_HD v3 bsdf_sample(const FlagView& fl, const M& m, bool inside, v3 wo, Rng& g)
+PTK_HD v3 bsdf_sample(const FlagView& fl, const M& m, bool inside, const LocalOut& out, Rng& g)
 {
   if (m.type == 4u /* DIELECTRIC, :225-240 */) {
     float r = rnd(g);
+    const v3 wo = out.get();
     float ri = inside ? (1.0f / m.ior) : m.ior;
     v3 N = V3(0.0f, 1.0f, 0.0f);
     float cos_theta = fminf(wo.y, 1.0f);
@@ -261,14 +270,14 @@ PTK_HD v3 bsdf_sample(const FlagView& fl, const M& m, bool inside, v3 wo, Rng& g
   }
   float r0 = rnd(g), r1 = rnd(g);
   if (m.type == 2u /* SPECULAR, :157-162 */)
-    return reflect(-wo, V3(0.0f, 1.0f, 0.0f)) + unit_vector_from(r0, r1) * m.roughness;
+    return reflect(-out.get(), V3(0.0f, 1.0f, 0.0f)) + unit_vector_from(r0, r1) * m.roughness;
   if (m.type == 16u /* MICROFACET */ && fl.importance_sample) {  // Sample_Beckmann, :57-67
     float alpha = sqf(m.roughness), alpha2 = sqf(alpha);
     float tan2 = -alpha2 * logf(1.0f - (r1 / kPi));  // tan^2(theta)
     float ct = 1.0f / sqrtf(1.0f + tan2);
     float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
     v3 H = spherical_dir(ct, st, r0);
-    return reflect(-wo, H);
+    return reflect(-out.get(), H);
   }
   // diffuse, :138-144: theta = acos(sqrt(r1))
   float ct = sqrtf(r1);
@@ -466,8 +475,10 @@ PTK_HD bool nee_setup(PathState& ps, const SceneView& sc, const FlagView& fl, co
     float t = sqrtf(r1);
     float u = 1.0f - t, v = r2 * t, w = 1.0f - u - v;
     q = ld3(light.p0) * u + ld3(light.p1) * v + ld3(light.p2) * w;
-    // what the shadow ray's hit record will carry: a light keeps its interpolated, unflipped normal
-    normal = ld3(light.n0) * u + ld3(light.n1) * v + ld3(light.n2) * w;
+    // what the shadow ray's hit record will carry: a light keeps its interpolated, unflipped normal (of three equal
+    // normals that is the normal itself, up to the rounding of u + v + w)
+    normal = ld3(light.n0);
+    if (!light.flat) normal = normal * u + ld3(light.n1) * v + ld3(light.n2) * w;
   } else {
     v3 c = ld3(light.p0);
     v3 n = normalize(s.point - c);
@@ -556,15 +567,15 @@ PTK_HD bool path_shade(PathState& ps, Stack& st, const SceneView& sc, const Flag
   }
   PTK_MARK("shade.frame");
   Frame fr = make_frame(s.normal);
-  v3 wo = to_local(fr, -d);
+  const LocalOut out = {fr, d};
   PTK_MARK("shade.sample");
-  v3 wi = bsdf_sample(fl, m, s.inside, wo, ps.g);
+  v3 wi = bsdf_sample(fl, m, s.inside, out, ps.g);
   PTK_MARK("shade.eval");
   bool specular = (m.flags & kMatSpecular) != 0;
   v3 scale = ps.beta * rr_weight;
   if (!fl.direct_light_sampling || ps.depth() == 0 || specular || ps.prev_specular) ps.L += scale * emission;
   v3 next_d = to_world(fr, wi);  // not renormalised, as in the reference (src/renderer.cpp:121)
-  ps.beta = scale * bsdf_eval(fl, m, albedo, wo, wi);
+  ps.beta = scale * (m.type == 16u ? bsdf_eval(fl, m, albedo, out.get(), wi) : bsdf_eval(fl, m, albedo, wi, wi));  // only the microfacet model reads V
   ps.prev_specular = specular;
   ps.tr.o = s.point;
   v3 to_light, pending;

@@ -52,7 +52,10 @@ int median_levels(int n)
   return l;
 }
 
-constexpr int kBins = 16;
+#ifndef PTK_SAH_BINS
+#define PTK_SAH_BINS 16
+#endif
+constexpr int kBins = PTK_SAH_BINS;
 constexpr float kTraversalCost = 1.0f;
 #ifndef PTK_SAH_INTERSECT_COST
 #define PTK_SAH_INTERSECT_COST 1.2f

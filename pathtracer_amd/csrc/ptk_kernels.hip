@@ -228,20 +228,19 @@ struct LdsStack {
 // the 1536 bytes have to come out of the traversal stacks (13 LDS entries per lane instead of 19), and that costs more
 // than the spills did: -0.7 % on the 82k-triangle scene, -1.2 % on the 1.3M-triangle scene, -0.2 % on the glass scene.
 // Hence off; -DPTK_PARK=1 -DPTK_STACK_DEPTH_TABLES=13 -DPTK_STACK_DEPTH_SHALLOW=16 -DPTK_STACK_ROOM=4 builds it.
-#ifndef PTK_PARK
-#define PTK_PARK 0
-#endif
+// (-DPTK_PARK=2 parks the light term alone, 768 bytes: -DPTK_PARK=2 -DPTK_STACK_DEPTH_TABLES=16 -DPTK_STACK_DEPTH_SHALLOW=19.)
 struct LdsPark {
   PTK_LDS_SPACE float* at;  // this lane's word 0
-  __device__ __forceinline__ void store(PathState&, v3 pending, v3 next_d) const
+  __device__ __forceinline__ void store(PathState& ps, v3 pending, v3 next_d) const
   {
     at[0] = pending.x; at[kBlock] = pending.y; at[2 * kBlock] = pending.z;
+    if (PTK_PARK == 2) { ps.next_d = next_d; return; }
     at[3 * kBlock] = next_d.x; at[4 * kBlock] = next_d.y; at[5 * kBlock] = next_d.z;
   }
-  __device__ __forceinline__ void load(const PathState&, v3& pending, v3& next_d) const
+  __device__ __forceinline__ void load(const PathState& ps, v3& pending, v3& next_d) const
   {
     pending = V3(at[0], at[kBlock], at[2 * kBlock]);
-    next_d = V3(at[3 * kBlock], at[4 * kBlock], at[5 * kBlock]);
+    next_d = PTK_PARK == 2 ? ps.next_d : V3(at[3 * kBlock], at[4 * kBlock], at[5 * kBlock]);
   }
 };
 
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
   using Mem = typename std::conditional<TINY, LdsMem, typename std::conditional<TABLES, TablesMem, GlobalMem>::type>::type;
   constexpr bool DEFER = PTK_DEFER_START != 0;
   constexpr bool PARK = PTK_PARK && !DEEP && !TINY;  // the waiting vectors of a path in LDS (LdsPark)
-  static_assert(!TABLES || kStackDepthTables > (PARK ? 13 : 19) || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes + (PARK ? kParkBytes : 0) <= 5 * 1280,
+  static_assert(!TABLES || kStackDepthTables > (PARK ? (PTK_PARK == 2 ? 16 : 13) : 19) || (kStackDepthTables + 3) * kBlock * 4 + kTableBytes + (PARK ? kParkBytes : 0) <= 5 * 1280,
                 "stack, pixel sums, tables (and parked vectors) share five LDS granules");
   using Park = typename std::conditional<PARK, LdsPark, ParkInState>::type;
   constexpr int kSceneChunks = (kTinyNodes * sizeof(NodePair) + kTinyPrims * (sizeof(PrimRec) + sizeof(ShadeRec)) +

@@ -52,7 +52,10 @@ constexpr int kShallowTreeDepth = kStackDepthShallow - 2;
 constexpr int kStackDepthTables = PTK_STACK_DEPTH_TABLES;
 constexpr int kTablesTreeDepth = kStackDepthTables - 2;
 constexpr int kTableBytes = 768;
-constexpr int kParkBytes = 6 * 64 * 4;  // two vectors per lane that wait in LDS while a shadow ray is traced (LdsPark in ptk_kernels.hip)
+#ifndef PTK_PARK
+#define PTK_PARK 0  // 1: the waiting light term and the next direction of a path in LDS, 2: the light term only
+#endif
+constexpr int kParkBytes = (PTK_PARK == 2 ? 3 : 6) * 64 * 4;  // vectors of a lane that wait in LDS while a shadow ray is traced (LdsPark in ptk_kernels.hip)
 // Tiny scenes (the Cornell box: 5 nodes, 12 triangles, 6 materials, 2 lights): the render kernel has a third form
 // that copies the whole scene except the texels into LDS when a workgroup starts and works from there - no
 // vector-memory instruction in the traversal, and none in shading but the texture fetches.  16 nodes (512 B) + 24

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../pathtracer_amd/csrc"
 mkdir -p ../variants
 for v in "$@"; do
   NAME=${v%%=*}; FLAGS=${v#*=}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ${BASEFLAGS--fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -fno-slp-vectorize -mllvm --sink-insts-to-avoid-spills} $FLAGS \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared ${BASEFLAGS--fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -fno-slp-vectorize -mllvm --sink-insts-to-avoid-spills -mllvm --amdgpu-schedule-relaxed-occupancy} $FLAGS \
     -o ../variants/libptk_${NAME}.so ptk_kernels.hip ptk_build.cpp ptk_lbvh.hip ptk_group.hip -ldl &
 done
 wait

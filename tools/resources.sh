@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel register / spill / LDS / occupancy table of ptk_kernels.hip (compiler remarks).  Extra arguments: compiler flags.
 cd "$(dirname "$0")/../pathtracer_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -fno-slp-vectorize -mllvm --sink-insts-to-avoid-spills "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-hip-fp32-correctly-rounded-divide-sqrt -fgpu-flush-denormals-to-zero -fno-slp-vectorize -mllvm --sink-insts-to-avoid-spills -mllvm --amdgpu-schedule-relaxed-occupancy "$@" \
   -Rpass-analysis=kernel-resource-usage -c ptk_kernels.hip -o /dev/null 2>&1 | python3 -c '
 import re,sys
 cur=None; rows=[]

@@ -22,7 +22,9 @@ __device__ bool lane_on(int mode, int lane)
   }
 }
 
-template <int WIDTH>  // bytes per lane: 16, 8, 4
+struct f3 { float x, y, z; };
+
+template <int WIDTH>  // bytes per lane: 16, 8, 4; 12 (one dwordx3); 32 (two 16-byte loads of one 32-byte record); 28 (16 + 12 of a 28-byte record)
 __global__ __launch_bounds__(64) void gather_kernel(const f4* table, int table_mask, int iters, int mode, float* out, int use_lds)
 {
   __shared__ f4 lds[256];  // 4 KB
@@ -38,10 +40,22 @@ __global__ __launch_bounds__(64) void gather_kernel(const f4* table, int table_m
         unsigned j = (idx + k * 97u) & table_mask;
         if (use_lds) {
           f4 v = lds[j & 255];
-          acc += v.x + v.w;
+          acc += (v.x + v.y) + (v.z + v.w);
         } else if (WIDTH == 16) {
           f4 v = table[j];
-          acc += v.x + v.w;
+          acc += (v.x + v.y) + (v.z + v.w);  // every component is used: the compiler must not narrow the load
+        } else if (WIDTH == 32) {
+          const f4* r = table + 2 * (j >> 1);
+          f4 v = r[0], w = r[1];
+          acc += ((v.x + v.y) + (v.z + v.w)) + ((w.x + w.y) + (w.z + w.w));
+        } else if (WIDTH == 28) {
+          const char* r = reinterpret_cast<const char*>(table) + 28u * (j >> 1);  // records of 28 bytes, 4-byte aligned
+          f4 v = *reinterpret_cast<const f4*>(r);
+          f3 w = *reinterpret_cast<const f3*>(r + 16);
+          acc += ((v.x + v.y) + (v.z + v.w)) + ((w.x + w.y) + w.z);
+        } else if (WIDTH == 12) {
+          f3 v = *reinterpret_cast<const f3*>(&table[j]);
+          acc += (v.x + v.y) + v.z;
         } else if (WIDTH == 8) {
           float2 v = *reinterpret_cast<const float2*>(&table[j]);
           acc += v.x + v.y;
@@ -71,12 +85,15 @@ int main()
   const int iters = 2000;
   const char* names[] = {"64 lanes", "lanes 0-31", "even lanes", "lanes 0-15", "every 4th lane", "lanes 0-7", "every 16th lane"};
   for (int lds = 0; lds < 2; lds++)
-    for (int width : {16, 8, 4}) {
+    for (int width : {16, 8, 4, 12, 32, 28}) {
       if (lds && width != 16) continue;
       for (int mode = 0; mode < 7; mode++) {
         for (int rep = 0; rep < 2; rep++) {
           hipEventRecord(a);
           if (width == 16) hipLaunchKernelGGL(gather_kernel<16>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
+          else if (width == 12) hipLaunchKernelGGL(gather_kernel<12>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
+          else if (width == 32) hipLaunchKernelGGL(gather_kernel<32>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
+          else if (width == 28) hipLaunchKernelGGL(gather_kernel<28>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
           else if (width == 8) hipLaunchKernelGGL(gather_kernel<8>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
           else hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(64), 0, 0, d, table_n - 1, iters, mode, out, lds);
           hipEventRecord(b);
@@ -84,7 +101,7 @@ int main()
         }
         float ms;
         hipEventElapsedTime(&ms, a, b);
-        // wave-instructions per CU: 20 waves x iters x 8
+        // wave-instructions per CU: 20 waves x iters x 8 (the 32- and 28-byte records: per record, two instructions)
         double per_cu = 20.0 * iters * 8.0;
         double cycles = ms * 1e-3 * 2.4e9 / per_cu;
         printf("%s %2d B/lane, %-16s: %8.3f ms, %6.1f cycles per wave-instruction per CU (at 2.4 GHz)\n", lds ? "LDS" : "L1 ", width,

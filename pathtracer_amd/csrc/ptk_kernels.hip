@@ -52,7 +52,7 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 #define PTK_MIN_WAVES 5     // __launch_bounds__ waves per SIMD of the render kernel's deep-tree form: 96 VGPRs
 #endif
 #ifndef PTK_MIN_WAVES_SHALLOW
-#define PTK_MIN_WAVES_SHALLOW 6  // ... and of its shallow-tree form: 80 VGPRs (6 of them spilled), 6400 bytes of LDS
+#define PTK_MIN_WAVES_SHALLOW 6  // ... and of its shallow-tree form: 80 VGPRs (3 spilled), 6400 bytes of LDS
 #endif
 // A frame whose tiles alone give the chip only a few rounds of waves ends with most CUs idle
 // while the slowest tiles finish, so a tile's samples are split over several workgroups.
@@ -226,7 +226,8 @@ struct LdsStack {
 // of lane l at base[k * 64 + l].  Kept in the path state they are live through every traversal loop, and at six
 // waves per SIMD that is six registers the compiler otherwise finds in scratch memory (7 spilled dwords -> 2).  Measured:
 // the 1536 bytes have to come out of the traversal stacks (13 LDS entries per lane instead of 19), and that costs more
-// than the spills did: -0.7 % on the 82k-triangle scene, -1.2 % on the 1.3M-triangle scene, -0.2 % on the glass scene.
+// than the spills did: -0.7 % on the 82k-triangle scene, -1.2 % on the 1.3M-triangle scene, -0.2 % on the glass scene
+// (-1.7 %, -3.1 %, -1.3 % since the build options brought the spills down to three).
 // Hence off; -DPTK_PARK=1 -DPTK_STACK_DEPTH_TABLES=13 -DPTK_STACK_DEPTH_SHALLOW=16 -DPTK_STACK_ROOM=4 builds it.
 // (-DPTK_PARK=2 parks the light term alone, 768 bytes: -DPTK_PARK=2 -DPTK_STACK_DEPTH_TABLES=16 -DPTK_STACK_DEPTH_SHALLOW=19.)
 struct LdsPark {

@@ -334,6 +334,17 @@ def main(args):
     for name, split, scaling in runs:
         results[name] = run_workload(name, args, ctx, torch, dist, dev, rank, world, with_cpu=(world == 1 and not args.no_cpu),
                                      split=split, scaling=scaling)
+    if world == 1 and args.workload == "all" and not args.no_4k:
+        # the frame that the N > 1 default shares among the GPUs (bmw at 3840x2160), on this one GPU and with few steps: the
+        # single-GPU figure that its top-level line compares with
+        import copy
+        a4 = copy.copy(args)
+        a4.sizes = dict(args.sizes)
+        a4.sizes["bmw"] = (3840, 2160, args.sizes["bmw"][2], args.sizes["bmw"][3])
+        a4.steps, a4.warmup = min(args.steps, 3), min(args.warmup, 1)
+        results["bmw_4k"] = run_workload("bmw", a4, ctx, torch, dist, dev, rank, world, with_cpu=False, split="spp", scaling="weak")
+        results["bmw_4k"]["steps"] = a4.steps
+        names.append("bmw_4k")
     if rank == 0:
         head = results[names[0]]
         out = {"metric": "Mrays/s", "value": head["value"], "unit": "Mrays/s",
@@ -385,6 +396,7 @@ def parse_args(argv=None):
     ap.add_argument("--builder", default=None, choices=["host", "device"],
                     help="tree builder (default: host surface-area-heuristic build; device: linear BVH built on the GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-4k", action="store_true", help="skip the 3840x2160 frame of the 1.3 M-triangle scene that the default run adds under extra")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time budget of each workload's baseline leg")
     args = ap.parse_args(argv)
     args.sizes = {}

@@ -298,15 +298,98 @@ __global__ __launch_bounds__(kBuildBlock) void fit_level_kernel(const float* __r
   nodes[i].x1 = b1.x; nodes[i].y1 = b1.y; nodes[i].z1 = b1.z;
 }
 
+// The nodes in use, level by level: list[begin .. end) holds one level, the inner children of its nodes are appended
+// behind `counter` (which starts at `end`).  Needed once the rotations below have moved subtrees between levels.
+__global__ __launch_bounds__(kBuildBlock) void expand_level_kernel(const NodePair* __restrict__ nodes, uint32_t* list,
+                                                                   uint32_t begin, uint32_t end, uint32_t* counter)
+{
+  uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= end) return;
+  const NodePair nd = nodes[list[k]];
+  if (nd.child0 >= 0) list[atomicAdd(counter, 1u)] = (uint32_t)nd.child0;
+  if (nd.child1 >= 0) list[atomicAdd(counter, 1u)] = (uint32_t)nd.child1;
+}
+
+// Tree rotations, as the host builder does them after its build (ptk_build.cpp): a child of a node trades places with a
+// grandchild on the other side when the inner child left behind gets a smaller box.  One level per launch, deepest
+// first, so that a thread owns its node and that node's two children; `level` is the level of these nodes (root = 1),
+// a trade pushes one subtree a level down and is only made where the tree stays within `limit` levels of inner nodes.
+// height[i]: levels of inner nodes from i down.
+#ifndef PTK_LBVH_ROTATION_PASSES
+#define PTK_LBVH_ROTATION_PASSES 2
+#endif
+constexpr int kRotationPasses = PTK_LBVH_ROTATION_PASSES;
+// A trade has to shrink the inner child's area by this part of it.  Measured on these trees: the few trades with large
+// gains are worth +1.7 % (82k triangles) and +2.8 % (1.3M triangles) of the frame rate, taking every trade with any
+// gain (tens of thousands more) loses 2 % again.
+#ifndef PTK_LBVH_ROTATION_MIN_GAIN
+#define PTK_LBVH_ROTATION_MIN_GAIN 0.2f
+#endif
+constexpr float kRotationMinGain = PTK_LBVH_ROTATION_MIN_GAIN;
+__global__ __launch_bounds__(kBuildBlock) void rotate_level_kernel(NodePair* nodes, const uint32_t* __restrict__ list,
+                                                                   uint32_t begin, uint32_t end, int level, int limit,
+                                                                   uint8_t* height, uint32_t* __restrict__ subtree, BoxGrid g,
+                                                                   uint32_t* applied)
+{
+  uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= end) return;
+  const uint32_t i = list[k];
+  NodePair N = nodes[i];
+  int32_t link[2] = {N.child0, N.child1};
+  QBox box[2] = {{N.x0, N.y0, N.z0}, {N.x1, N.y1, N.z1}};
+  int hgt[2] = {link[0] >= 0 ? (int)height[link[0]] : 0, link[1] >= 0 ? (int)height[link[1]] : 0};
+  float best = 0.0f;
+  int best_side = -1, best_up = -1;
+  QBox best_box = box[0];
+  for (int side = 0; side < 2; side++) {  // link[side] keeps one of its children and takes link[1 - side]
+    if (link[side] < 0 || level + 1 + hgt[1 - side] > limit) continue;
+    const NodePair C = nodes[link[side]];
+    const QBox gb[2] = {{C.x0, C.y0, C.z0}, {C.x1, C.y1, C.z1}};
+    const float now = q_half_area(box[side], g);
+    for (int up = 0; up < 2; up++) {
+      const QBox& stays = gb[1 - up];
+      const QBox u{q_union(box[1 - side].x, stays.x), q_union(box[1 - side].y, stays.y), q_union(box[1 - side].z, stays.z)};
+      const float gain = now - q_half_area(u, g);
+      if (gain > best && gain > kRotationMinGain * now) { best = gain; best_side = side; best_up = up; best_box = u; }
+    }
+  }
+  if (best_side >= 0) {
+    const int side = best_side, other = 1 - side, up = best_up;
+    const int32_t c = link[side];
+    NodePair C = nodes[c];
+    const int32_t up_link = up ? C.child1 : C.child0, stays_link = up ? C.child0 : C.child1;
+    const QBox up_box = up ? QBox{C.x1, C.y1, C.z1} : QBox{C.x0, C.y0, C.z0};
+    // c: the grandchild that moves up makes room for the node's other child
+    if (up) { C.child1 = link[other]; C.x1 = box[other].x; C.y1 = box[other].y; C.z1 = box[other].z; }
+    else { C.child0 = link[other]; C.x0 = box[other].x; C.y0 = box[other].y; C.z0 = box[other].z; }
+    nodes[c] = C;
+    const int stays_h = stays_link >= 0 ? (int)height[stays_link] : 0;
+    hgt[side] = 1 + max(hgt[other], stays_h);
+    height[c] = (uint8_t)hgt[side];
+    subtree[c] = 1u + (link[other] >= 0 ? subtree[link[other]] : 0u) + (stays_link >= 0 ? subtree[stays_link] : 0u);
+    box[side] = best_box;
+    link[other] = up_link;
+    box[other] = up_box;
+    hgt[other] = up_link >= 0 ? (int)height[up_link] : 0;
+    N.child0 = link[0]; N.x0 = box[0].x; N.y0 = box[0].y; N.z0 = box[0].z;
+    N.child1 = link[1]; N.x1 = box[1].x; N.y1 = box[1].y; N.z1 = box[1].z;
+    nodes[i] = N;
+    atomicAdd(applied, 1u);
+  }
+  height[i] = (uint8_t)(1 + max(hgt[0], hgt[1]));
+  subtree[i] = 1u + (link[0] >= 0 ? subtree[link[0]] : 0u) + (link[1] >= 0 ? subtree[link[1]] : 0u);
+}
+
 // Final positions, top-down: depth-first order (a node, its first child's whole subtree, then the second
-// child's), which keeps the lower levels of every subtree together in memory.
+// child's), which keeps the lower levels of every subtree together in memory.  list[begin .. end): one level.
 __global__ __launch_bounds__(kBuildBlock) void number_level_kernel(const NodePair* __restrict__ nodes,
-                                                                   const uint32_t* __restrict__ live,
+                                                                   const uint32_t* __restrict__ list,
                                                                    const uint32_t* __restrict__ subtree, uint32_t begin,
                                                                    uint32_t end, uint32_t* new_index)
 {
-  uint32_t i = begin + blockIdx.x * kBuildBlock + threadIdx.x;
-  if (i >= end || !live[i]) return;
+  uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= end) return;
+  const uint32_t i = list[k];
   const uint32_t at = new_index[i];
   const int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
   if (c0 >= 0) new_index[c0] = at + 1u;
@@ -435,9 +518,57 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
         d_boxes, order, nodes_full, levels[l].first, levels[l].second, live, subtree, grid, (uint32_t)n_triangles);
     LBVH_HIP(hipGetLastError());
   }
-  for (size_t l = 0; l < levels.size(); l++) {
-    number_level_kernel<<<blocks_for(levels[l].second - levels[l].first), kBuildBlock, 0, stream>>>(
-        nodes_full, live, subtree, levels[l].first, levels[l].second, new_index);
+  // the nodes in use by level (merging has dropped some; rotations move subtrees between levels)
+  uint32_t* list = nullptr;
+  uint8_t* height = nullptr;
+  uint32_t* applied = nullptr;
+  LBVH_HIP(scratch.alloc((void**)&list, n_built * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&height, n_built * sizeof(uint8_t)));
+  LBVH_HIP(scratch.alloc((void**)&applied, sizeof(uint32_t)));
+  std::vector<std::pair<uint32_t, uint32_t>> lists;  // positions in `list`
+  auto relevel = [&]() -> std::string {
+    lists.clear();
+    const uint32_t zero = 0u;
+    LBVH_HIP(hipMemcpyAsync(list, &zero, sizeof zero, hipMemcpyHostToDevice, stream));  // the root
+    LBVH_HIP(hipMemcpyAsync(counter, &one, sizeof one, hipMemcpyHostToDevice, stream));
+    uint32_t lb = 0, le = 1;
+    while (lb < le) {
+      if ((int)lists.size() >= kMaxTreeDepth) return "internal: device tree deeper than the traversal stack allows";
+      expand_level_kernel<<<blocks_for(le - lb), kBuildBlock, 0, stream>>>(nodes_full, list, lb, le, counter);
+      LBVH_HIP(hipGetLastError());
+      uint32_t total = 0;
+      LBVH_HIP(hipMemcpyAsync(&total, counter, sizeof total, hipMemcpyDeviceToHost, stream));
+      LBVH_HIP(hipStreamSynchronize(stream));
+      if (total < le || total > n_built) return "internal: device tree level lists out of range";
+      lists.emplace_back(lb, le);
+      lb = le;
+      le = total;
+    }
+    return std::string();
+  };
+  {
+    std::string why = relevel();
+    if (!why.empty()) return why;
+  }
+  const int depth_limit = (int)lists.size();  // rotations keep the tree as deep as it is
+  for (int pass = 0; pass < kRotationPasses; pass++) {
+    LBVH_HIP(hipMemsetAsync(applied, 0, sizeof(uint32_t), stream));
+    for (size_t l = lists.size(); l-- > 0;) {
+      rotate_level_kernel<<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
+          nodes_full, list, lists[l].first, lists[l].second, (int)l + 1, depth_limit, height, subtree, grid, applied);
+      LBVH_HIP(hipGetLastError());
+    }
+    uint32_t n_applied = 0;
+    LBVH_HIP(hipMemcpyAsync(&n_applied, applied, sizeof n_applied, hipMemcpyDeviceToHost, stream));
+    LBVH_HIP(hipStreamSynchronize(stream));
+    if (std::getenv("PTK_LBVH_REPORT")) fprintf(stderr, "[ptk lbvh] rotation pass %d: %u trades\n", pass, n_applied);
+    if (n_applied == 0u) break;
+    std::string why = relevel();
+    if (!why.empty()) return why;
+  }
+  for (size_t l = 0; l < lists.size(); l++) {
+    number_level_kernel<<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
+        nodes_full, list, subtree, lists[l].first, lists[l].second, new_index);
     LBVH_HIP(hipGetLastError());
   }
   uint32_t n_nodes = 0;
@@ -489,7 +620,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   out.nodes = nodes;
   out.prims = prims;
   out.n_nodes = (int32_t)n_nodes;
-  out.max_depth = (int32_t)levels.size();  // leaves of the deepest inner level
+  out.max_depth = (int32_t)lists.size();  // leaves of the deepest inner level
   out.max_leaf = kMaxLeafSize;
   out.build_ms = ms;
   return std::string();

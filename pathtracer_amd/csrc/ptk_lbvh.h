@@ -2,8 +2,9 @@
 // BVH::construct (src/scene.cpp:80, src/bvh.cpp:54-83) that the host builder of ptk_build.cpp
 // otherwise does, for callers that load or change large scenes and cannot wait for a host build.
 // Same node and primitive layout (ptk_layout.h), same depth and leaf-size limits, so the traversal
-// kernels run unchanged; the tree is a linear BVH (primitives sorted along a space-filling curve,
-// ranges split where the sort key's highest differing bit flips), not a surface-area-heuristic one.
+// kernels run unchanged; the tree is a linear BVH (primitives sorted by size class and along a space-filling
+// curve, ranges split where the sort key's highest differing bit flips, small ranges by surface area, a few
+// rotations at the end), not a surface-area-heuristic one.
 #pragma once
 
 #include <hip/hip_runtime.h>

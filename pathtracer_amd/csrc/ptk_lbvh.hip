@@ -1,10 +1,11 @@
 // On-device tree construction (see ptk_lbvh.h).
 //
-//   1. key_kernel      one 64-bit sort key per primitive: 16 bits each of the box centre's x, y, z inside
-//                      the scene's centre bounds and of the box diagonal relative to the longest one,
-//                      interleaved size-first.  Carrying the size in the key keeps the few large
-//                      primitives of a scene (walls, floors) together near the top of the tree instead
-//                      of scattering them over leaves of small ones, whose boxes they would blow up.
+//   1. size_histogram_kernel + key_kernel: one 64-bit sort key per primitive - the box's size class in the top four
+//      bits, then 20 bits each of the box centre's x, y, z inside the scene's centre bounds, interleaved.  The size
+//      classes keep the few large primitives of a scene (walls, floors) together at the top of the tree instead
+//      of scattering them over leaves of small ones, whose boxes they would blow up; they are the groups that empty
+//      bins of a logarithmic size histogram keep apart, so that no class boundary runs through a population of
+//      similar primitives.
 //   2. rocprim radix sort of (key, primitive) pairs.
 //   3. split_level_kernel, one launch per tree level: every node of the level splits its range of
 //      the sorted sequence where the highest differing key bit flips (binary search), or at the
@@ -15,8 +16,11 @@
 //      the child's own record (inner nodes); subtrees of at most kMaxLeafSize primitives are merged into one
 //      leaf where the surface-area heuristic prefers that, and the four grandchildren of a node are paired
 //      anew where another pairing has less surface area (regroup).
-//   5. number_level_kernel, top level first, gives the nodes still in use their final depth-first positions
-//      (from the subtree sizes the fitting pass left); compact_kernel moves them there and renumbers the links; gather_kernel: primitive records into leaf order.
+//   5. expand_level_kernel lists the nodes in use level by level; rotate_level_kernel, deepest level first, trades
+//      a child for a grandchild of the other side where that shrinks the inner child by a fifth (two passes).
+//   6. number_level_kernel, top level first, gives the nodes still in use their final depth-first positions
+//      (from the subtree sizes that the passes before left); compact_kernel moves them there and renumbers the links;
+//      gather_kernel: primitive records into leaf order.
 #include "ptk_lbvh.h"
 
 #include <cstdio>
@@ -41,35 +45,62 @@ struct KeyParams {
   float size_scale;
 };
 
-// bit k of a 16-bit value -> bit 4k
-__device__ inline uint64_t spread4(uint32_t v)
+// bit k of a 20-bit value -> bit 3k
+__device__ inline uint64_t spread3(uint32_t v)
 {
-  uint64_t x = v & 0xffffu;
-  x = (x | (x << 24)) & 0x000000ff000000ffull;
-  x = (x | (x << 12)) & 0x000f000f000f000full;
-  x = (x | (x << 6)) & 0x0303030303030303ull;
-  x = (x | (x << 3)) & 0x1111111111111111ull;
+  uint64_t x = v & 0xfffffu;
+  x = (x | (x << 32)) & 0x001f00000000ffffull;
+  x = (x | (x << 16)) & 0x001f0000ff0000ffull;
+  x = (x | (x << 8)) & 0x100f00f00f00f00full;
+  x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
   return x;
 }
 
-__device__ inline uint32_t quantise16(float v)
+// Sizes are looked at on a logarithmic scale: bin k holds the boxes whose diagonal is 2^(-k/2) .. 2^(-(k+1)/2) of the
+// largest one's (kp.size_scale = 1 / largest diagonal).
+constexpr int kSizeBins = 64;
+__device__ inline int size_bin(float relative_diagonal)
 {
-  float q = fminf(fmaxf(v, 0.0f), 65535.0f);
-  return (uint32_t)q;
+  const int b = relative_diagonal > 0.0f ? (int)(-2.0f * log2f(relative_diagonal)) : kSizeBins - 1;
+  return min(max(b, 0), kSizeBins - 1);
 }
 
+__global__ __launch_bounds__(kBuildBlock) void size_histogram_kernel(const float* __restrict__ boxes, int32_t n, KeyParams kp,
+                                                                     uint32_t* __restrict__ histogram)
+{
+  __shared__ uint32_t local[kSizeBins];
+  if (threadIdx.x < kSizeBins) local[threadIdx.x] = 0u;
+  __syncthreads();
+  int32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
+  if (i < n) {
+    const float* b = boxes + 6 * (size_t)i;
+    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+    atomicAdd(&local[size_bin(sqrtf(ex * ex + ey * ey + ez * ez) * kp.size_scale)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kSizeBins && local[threadIdx.x]) atomicAdd(&histogram[threadIdx.x], local[threadIdx.x]);
+}
+
+// Sort key: the box's size class in the top four bits, then its centre as a 60-bit position on a space-filling curve.
+// size_class[bin]: which class a size bin belongs to (class 0 = the largest boxes); classes are the groups of
+// occupied bins that empty bins keep apart (see build_device_tree), so that a class boundary never runs through a
+// population of similar boxes - a boundary inside the mesh's own range of triangle sizes would make two trees of
+// interleaved triangles over the same space.
 __global__ __launch_bounds__(kBuildBlock) void key_kernel(const float* __restrict__ boxes, int32_t n, KeyParams kp,
+                                                          const uint8_t* __restrict__ size_class,
                                                           uint64_t* __restrict__ keys, uint32_t* __restrict__ order)
 {
   int32_t i = blockIdx.x * kBuildBlock + threadIdx.x;
   if (i >= n) return;
   const float* b = boxes + 6 * (size_t)i;
   float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
-  uint32_t qx = quantise16((0.5f * (b[0] + b[3]) - kp.lo[0]) * kp.scale[0]);
-  uint32_t qy = quantise16((0.5f * (b[1] + b[4]) - kp.lo[1]) * kp.scale[1]);
-  uint32_t qz = quantise16((0.5f * (b[2] + b[5]) - kp.lo[2]) * kp.scale[2]);
-  uint32_t qs = quantise16(sqrtf(ex * ex + ey * ey + ez * ez) * kp.size_scale);
-  keys[i] = (spread4(qs) << 3) | (spread4(qx) << 2) | (spread4(qy) << 1) | spread4(qz);
+  // size class first, then 20 bits per axis of the box centre
+  const uint32_t cls = size_class[size_bin(sqrtf(ex * ex + ey * ey + ez * ez) * kp.size_scale)];
+  const uint32_t px = (uint32_t)fminf(fmaxf((0.5f * (b[0] + b[3]) - kp.lo[0]) * kp.scale[0], 0.0f), 1048575.0f);
+  const uint32_t py = (uint32_t)fminf(fmaxf((0.5f * (b[1] + b[4]) - kp.lo[1]) * kp.scale[1], 0.0f), 1048575.0f);
+  const uint32_t pz = (uint32_t)fminf(fmaxf((0.5f * (b[2] + b[5]) - kp.lo[2]) * kp.scale[2], 0.0f), 1048575.0f);
+  keys[i] = ((uint64_t)cls << 60) | (spread3(px) << 2) | (spread3(py) << 1) | spread3(pz);
   order[i] = (uint32_t)i;
 }
 
@@ -479,8 +510,36 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
     kp.lo[k] = centroid_lo[k];
     kp.scale[k] = ext > 0.f ? 65535.0f / ext : 0.f;
   }
-  kp.size_scale = max_diagonal > 0.f ? 65535.0f / max_diagonal : 0.f;
-  key_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_boxes, n, kp, keys_in, order_in);
+  kp.size_scale = max_diagonal > 0.f ? 1.0f / max_diagonal : 0.f;
+  // size classes: groups of occupied size bins with at least kClassGap empty bins (a factor of 2^(kClassGap/2) in
+  // size) between them, at most sixteen (further groups join the last)
+  uint32_t* histogram = nullptr;
+  uint8_t* size_class = nullptr;
+  LBVH_HIP(scratch.alloc((void**)&histogram, kSizeBins * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&size_class, kSizeBins));
+  LBVH_HIP(hipMemsetAsync(histogram, 0, kSizeBins * sizeof(uint32_t), stream));
+  size_histogram_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_boxes, n, kp, histogram);
+  LBVH_HIP(hipGetLastError());
+  {
+    uint32_t h[kSizeBins];
+    uint8_t cls[kSizeBins];
+    LBVH_HIP(hipMemcpyAsync(h, histogram, sizeof h, hipMemcpyDeviceToHost, stream));
+    LBVH_HIP(hipStreamSynchronize(stream));
+    constexpr int kClassGap = 4;
+    int current = 0, empty_run = 0;
+    bool seen = false;
+    for (int b = 0; b < kSizeBins; b++) {
+      if (h[b] == 0u) { empty_run++; cls[b] = (uint8_t)current; continue; }
+      if (seen && empty_run >= kClassGap && current < 15) current++;
+      seen = true;
+      empty_run = 0;
+      cls[b] = (uint8_t)current;
+    }
+    LBVH_HIP(hipMemcpyAsync(size_class, cls, sizeof cls, hipMemcpyHostToDevice, stream));
+    LBVH_HIP(hipStreamSynchronize(stream));  // cls lives on this stack frame
+  }
+  for (int k = 0; k < 3; k++) kp.scale[k] *= 16.0f;  // 20 bits per axis
+  key_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_boxes, n, kp, size_class, keys_in, order_in);
   LBVH_HIP(hipGetLastError());
   LBVH_HIP(rocprim::radix_sort_pairs(sort_temp, temp_bytes, keys_in, keys, order_in, order, (size_t)un, 0u, 64u, stream));
 

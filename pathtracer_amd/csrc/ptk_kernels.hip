@@ -34,7 +34,11 @@ constexpr int kTile = 8;    // a workgroup renders an 8x8 pixel tile
 // 12: -2%, 20: -1%, 24: -3%; lit 4: same, 16: -1%; shade 16: -1%, 32: -1%; item 4: -1%, 16: -3%;
 // 4 waves per SIMD (109 VGPRs, none spilled): -8%.  Swept again for the 6-wave form: the same values stay best.
 #ifndef PTK_DESCEND_MIN
-#define PTK_DESCEND_MIN 16  // leave the descend loop when fewer lanes than this are at an inner node
+#define PTK_DESCEND_MIN 20  // leave the descend loop when fewer lanes than this are at an inner node (measured again with the
+                            // rotated trees: 20 against 16 is +0.2 % / +1.1 % on the two mesh scenes, 12 and 24 lose)
+#endif
+#ifndef PTK_DESCEND_MIN_TINY
+#define PTK_DESCEND_MIN_TINY 16  // ... in the whole-scene-in-LDS form (20: -0.7 % on the Cornell box), and in the ray-batch kernel
 #endif
 #ifndef PTK_LIT_MIN
 #define PTK_LIT_MIN 8       // consume finished shadow rays once this many lanes hold one
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kBlock, FORM == kFormDeep ? PTK_MIN_WAVES : PTK_MIN
       // Evaluated eagerly: one branch instead of three.  (The compiler forms "n_want < kDescendMin" with a 64-bit VECTOR
       // compare; the same test spelled out as two scalar instructions makes the loop 1 % slower: a wave issues its
       // instructions one after the other whatever unit they are for, and the scalar chain of a step is the longer one.)
-      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) return true;
+      if ((n_want == 0) | ((n_want < (TINY ? PTK_DESCEND_MIN_TINY : kDescendMin)) & any_held)) return true;
       PTK_PHASE(ph[0]++; ph[1] += n_want;)
       if (want) trav_inner<S, STATS, Mem>(ps.tr, s, sc, cnt, mem);
 #pragma unroll
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(kBlock, PTK_INTERSECT_WAVES) void intersect_kernel(
       const bool want = trav_at_inner(tr);
       const int n_want = __popcll(__ballot(want));
       const bool any_held = __ballot(held != kTravDone) != 0ull;
-      if ((n_want == 0) | ((n_want < kDescendMin) & any_held)) break;  // evaluated eagerly: one branch instead of three
+      if ((n_want == 0) | ((n_want < PTK_DESCEND_MIN_TINY) & any_held)) break;  // evaluated eagerly: one branch instead of three
       if (want) trav_inner<LdsStack, STATS>(tr, st, sc, cnt);
     }
     if (held != kTravDone) {

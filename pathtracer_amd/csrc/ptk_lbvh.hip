@@ -16,11 +16,11 @@
 //      the child's own record (inner nodes); subtrees of at most kMaxLeafSize primitives are merged into one
 //      leaf where the surface-area heuristic prefers that, and the four grandchildren of a node are paired
 //      anew where another pairing has less surface area (regroup).
-//   5. expand_level_kernel lists the nodes in use level by level; rotate_level_kernel, deepest level first, trades
-//      a child for a grandchild of the other side where that shrinks the inner child by a fifth (two passes).
-//   6. number_level_kernel, top level first, gives the nodes still in use their final depth-first positions
-//      (from the subtree sizes that the passes before left); compact_kernel moves them there and renumbers the links;
-//      gather_kernel: primitive records into leaf order.
+//   5. expand_level_kernel lists the nodes in use level by level; treelet_level_kernel, deepest level first, replaces
+//      the tree over the six largest subtrees below every node by the cheapest one (two passes).
+//   6. count_level_kernel (primitives below every node), then number_level_kernel, top level first, gives the nodes
+//      still in use their final depth-first positions and the leaves their primitive ranges in the same order;
+//      compact_kernel moves the nodes there and renumbers the links; gather_kernel: primitive records into leaf order.
 #include "ptk_lbvh.h"
 
 #include <cstdio>
@@ -411,20 +411,177 @@ __global__ __launch_bounds__(kBuildBlock) void rotate_level_kernel(NodePair* nod
   subtree[i] = 1u + (link[0] >= 0 ? subtree[link[0]] : 0u) + (link[1] >= 0 ? subtree[link[1]] : 0u);
 }
 
+// Treelet restructuring (after Karras and Aila, "Fast parallel construction of high-quality bounding volume
+// hierarchies"): below every node a treelet of up to K subtrees is opened (always the inner node with the largest
+// box next) and the binary tree over those subtrees with the least inner surface area - found by dynamic programming
+// over their subsets - replaces the one that was there.  A rotation is the case K = 3.  One level per launch, deepest
+// first: a thread owns its node and everything below it.  Trees that would exceed `limit` levels are left alone.
+// Measured (82k / 1.3M triangles): treelets of 6, two passes: box tests per ray 21.5 -> 20.0 and 24.9 -> 23.4, frame rate
+// +2.2 % / +0.8 %, build 8.5 -> 11.9 ms and 11.7 -> 17.7 ms; of 7: +2.3 % / +1.1 % for 17 and 26 ms; of 5: slower
+// frames unless small gains are refused.  0 builds the rotations alone.
+#ifndef PTK_LBVH_TREELET
+#define PTK_LBVH_TREELET 6  // subtrees per treelet
+#endif
+#ifndef PTK_LBVH_TREELET_MIN_GAIN
+#define PTK_LBVH_TREELET_MIN_GAIN 0.0f
+#endif
+template <int K>
+__global__ __launch_bounds__(kBuildBlock) void treelet_level_kernel(NodePair* nodes, const uint32_t* __restrict__ list,
+                                                                    uint32_t begin, uint32_t end, int level, int limit,
+                                                                    uint8_t* height, uint32_t* __restrict__ subtree, BoxGrid g,
+                                                                    uint32_t* applied)
+{
+  uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= end) return;
+  const uint32_t i = list[k];
+  constexpr int kSets = 1 << K;
+  int32_t sub[K];
+  QBox sb[K];
+  int32_t inner[K];
+  {
+    const NodePair N = nodes[i];
+    sub[0] = N.child0; sb[0] = QBox{N.x0, N.y0, N.z0};
+    sub[1] = N.child1; sb[1] = QBox{N.x1, N.y1, N.z1};
+  }
+  int n_sub = 2, n_inner = 1;
+  inner[0] = (int32_t)i;
+  float current = 0.0f;  // surface area of the treelet's inner nodes below its root
+  while (n_sub < K) {
+    int open = -1;
+    float largest = -1.0f;
+    for (int j = 0; j < n_sub; j++) {
+      if (sub[j] < 0) continue;
+      const float a = q_half_area(sb[j], g);
+      if (a > largest) { largest = a; open = j; }
+    }
+    if (open < 0) break;
+    const int32_t c = sub[open];
+    const NodePair C = nodes[c];
+    inner[n_inner++] = c;
+    current += largest;
+    sub[open] = C.child0; sb[open] = QBox{C.x0, C.y0, C.z0};
+    sub[n_sub] = C.child1; sb[n_sub] = QBox{C.x1, C.y1, C.z1};
+    n_sub++;
+  }
+  bool changed = false;
+  if (n_sub >= 3) {
+    const uint32_t full = (1u << n_sub) - 1u;
+    QBox ub[kSets];
+    float cost[kSets];
+    uint8_t split[kSets];
+    for (uint32_t m = 1; m <= full; m++) {
+      const int low = __ffs((int)m) - 1;
+      const uint32_t rest = m & (m - 1u);
+      if (rest == 0u) { ub[m] = sb[low]; cost[m] = 0.0f; split[m] = 0; continue; }
+      ub[m] = QBox{q_union(ub[rest].x, sb[low].x), q_union(ub[rest].y, sb[low].y), q_union(ub[rest].z, sb[low].z)};
+      float best = 3.0e38f;
+      uint32_t best_part = 0u;
+      for (uint32_t a = rest; a != 0u; a = (a - 1u) & rest) {  // a: a part without m's lowest member
+        const float c = cost[m ^ a] + cost[a];
+        if (c < best) { best = c; best_part = m ^ a; }
+      }
+      cost[m] = best + (m == full ? 0.0f : q_half_area(ub[m], g));
+      split[m] = (uint8_t)best_part;
+    }
+    if (cost[full] < current * (1.0f - PTK_LBVH_TREELET_MIN_GAIN)) {
+      // the inner nodes of the new treelet, root first; a node's children come later in the list
+      uint32_t tm[K];      // subset
+      int th[K];           // levels of inner nodes from it down (filled in below)
+      uint32_t ts[K];      // inner nodes in use from it down
+      int td[K];           // depth inside the treelet
+      int n_t = 0;
+      tm[n_t] = full; td[n_t] = 0; n_t++;
+      bool fits = true;
+      for (int t = 0; t < n_t; t++) {
+        const uint32_t parts[2] = {split[tm[t]], tm[t] ^ split[tm[t]]};
+        for (uint32_t part : parts) {
+          if (part & (part - 1u)) { tm[n_t] = part; td[n_t] = td[t] + 1; n_t++; }
+          else {
+            const int32_t link = sub[__ffs((int)part) - 1];
+            const int below = link >= 0 ? (int)height[link] : 0;
+            if (level + td[t] + below > limit) fits = false;  // the deepest level of inner nodes under this subtree
+          }
+        }
+      }
+      if (fits) {
+        for (int t = n_t - 1; t >= 0; t--) {
+          const uint32_t parts[2] = {split[tm[t]], tm[t] ^ split[tm[t]]};
+          int32_t link[2];
+          int below[2];
+          uint32_t count[2];
+          for (int c = 0; c < 2; c++) {
+            if (parts[c] & (parts[c] - 1u)) {
+              int u = t + 1;
+              while (tm[u] != parts[c]) u++;
+              link[c] = inner[u]; below[c] = th[u]; count[c] = ts[u];
+            } else {
+              link[c] = sub[__ffs((int)parts[c]) - 1];
+              below[c] = link[c] >= 0 ? (int)height[link[c]] : 0;
+              count[c] = link[c] >= 0 ? subtree[link[c]] : 0u;
+            }
+          }
+          th[t] = 1 + max(below[0], below[1]);
+          ts[t] = 1u + count[0] + count[1];
+          NodePair R;
+          R.x0 = ub[parts[0]].x; R.y0 = ub[parts[0]].y; R.z0 = ub[parts[0]].z; R.child0 = link[0];
+          R.x1 = ub[parts[1]].x; R.y1 = ub[parts[1]].y; R.z1 = ub[parts[1]].z; R.child1 = link[1];
+          nodes[inner[t]] = R;
+          height[inner[t]] = (uint8_t)th[t];
+          subtree[inner[t]] = ts[t];
+        }
+        changed = true;
+        atomicAdd(applied, 1u);
+      }
+    }
+  }
+  if (!changed) {
+    const NodePair N = nodes[i];
+    const int h0 = N.child0 >= 0 ? (int)height[N.child0] : 0, h1 = N.child1 >= 0 ? (int)height[N.child1] : 0;
+    height[i] = (uint8_t)(1 + max(h0, h1));
+    subtree[i] = 1u + (N.child0 >= 0 ? subtree[N.child0] : 0u) + (N.child1 >= 0 ? subtree[N.child1] : 0u);
+  }
+}
+
+// Primitives below every node, deepest level first (list[begin .. end): one level).
+__global__ __launch_bounds__(kBuildBlock) void count_level_kernel(const NodePair* __restrict__ nodes,
+                                                                  const uint32_t* __restrict__ list, uint32_t begin,
+                                                                  uint32_t end, uint32_t* __restrict__ prims_below)
+{
+  uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
+  if (k >= end) return;
+  const uint32_t i = list[k];
+  const int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
+  prims_below[i] = (c0 >= 0 ? prims_below[c0] : leaf_count(c0)) + (c1 >= 0 ? prims_below[c1] : leaf_count(c1));
+}
+
 // Final positions, top-down: depth-first order (a node, its first child's whole subtree, then the second
 // child's), which keeps the lower levels of every subtree together in memory.  list[begin .. end): one level.
-__global__ __launch_bounds__(kBuildBlock) void number_level_kernel(const NodePair* __restrict__ nodes,
-                                                                   const uint32_t* __restrict__ list,
+// The primitives follow the same order: a node's range starts at prim_first, its first child's primitives come first;
+// leaves are re-pointed at their new ranges and new_order says which primitive goes where.  (The sort order was the
+// order of the leaves as long as the tree was the one the splits had made; rotations and regrouping moved subtrees.)
+__global__ __launch_bounds__(kBuildBlock) void number_level_kernel(NodePair* nodes, const uint32_t* __restrict__ list,
                                                                    const uint32_t* __restrict__ subtree, uint32_t begin,
-                                                                   uint32_t end, uint32_t* new_index)
+                                                                   uint32_t end, uint32_t* new_index,
+                                                                   const uint32_t* __restrict__ prims_below, uint32_t* prim_first,
+                                                                   const uint32_t* __restrict__ order, uint32_t* __restrict__ new_order)
 {
   uint32_t k = begin + blockIdx.x * kBuildBlock + threadIdx.x;
   if (k >= end) return;
   const uint32_t i = list[k];
   const uint32_t at = new_index[i];
-  const int32_t c0 = nodes[i].child0, c1 = nodes[i].child1;
-  if (c0 >= 0) new_index[c0] = at + 1u;
-  if (c1 >= 0) new_index[c1] = at + 1u + (c0 >= 0 ? subtree[c0] : 0u);
+  int32_t c[2] = {nodes[i].child0, nodes[i].child1};
+  if (c[0] >= 0) new_index[c[0]] = at + 1u;
+  if (c[1] >= 0) new_index[c[1]] = at + 1u + (c[0] >= 0 ? subtree[c[0]] : 0u);
+  uint32_t first = prim_first[i];
+  for (int j = 0; j < 2; j++) {
+    if (c[j] >= 0) { prim_first[c[j]] = first; first += prims_below[c[j]]; continue; }
+    const uint32_t old_first = leaf_first(c[j]), count = leaf_count(c[j]);
+    for (uint32_t p = 0; p < count; p++) new_order[first + p] = order[old_first + p];
+    c[j] = leaf_link(first, count, leaf_has_spheres(c[j]));
+    first += count;
+  }
+  nodes[i].child0 = c[0];
+  nodes[i].child1 = c[1];
 }
 
 // Nodes in use move to their final, dense positions; inner links follow.
@@ -613,8 +770,13 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   for (int pass = 0; pass < kRotationPasses; pass++) {
     LBVH_HIP(hipMemsetAsync(applied, 0, sizeof(uint32_t), stream));
     for (size_t l = lists.size(); l-- > 0;) {
+#if PTK_LBVH_TREELET >= 3
+      treelet_level_kernel<PTK_LBVH_TREELET><<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
+          nodes_full, list, lists[l].first, lists[l].second, (int)l + 1, depth_limit, height, subtree, grid, applied);
+#else
       rotate_level_kernel<<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
           nodes_full, list, lists[l].first, lists[l].second, (int)l + 1, depth_limit, height, subtree, grid, applied);
+#endif
       LBVH_HIP(hipGetLastError());
     }
     uint32_t n_applied = 0;
@@ -625,9 +787,19 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
     std::string why = relevel();
     if (!why.empty()) return why;
   }
+  uint32_t *prims_below = nullptr, *prim_first = nullptr;
+  LBVH_HIP(scratch.alloc((void**)&prims_below, n_built * sizeof(uint32_t)));
+  LBVH_HIP(scratch.alloc((void**)&prim_first, n_built * sizeof(uint32_t)));
+  LBVH_HIP(hipMemsetAsync(prim_first, 0, sizeof(uint32_t), stream));  // the root's range starts at 0
+  for (size_t l = lists.size(); l-- > 0;) {
+    count_level_kernel<<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
+        nodes_full, list, lists[l].first, lists[l].second, prims_below);
+    LBVH_HIP(hipGetLastError());
+  }
+  uint32_t* new_order = order_in;  // (the unsorted order is no longer needed)
   for (size_t l = 0; l < lists.size(); l++) {
     number_level_kernel<<<blocks_for(lists[l].second - lists[l].first), kBuildBlock, 0, stream>>>(
-        nodes_full, list, subtree, lists[l].first, lists[l].second, new_index);
+        nodes_full, list, subtree, lists[l].first, lists[l].second, new_index, prims_below, prim_first, order, new_order);
     LBVH_HIP(hipGetLastError());
   }
   uint32_t n_nodes = 0;
@@ -642,7 +814,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
   compact_kernel<<<blocks_for(n_built), kBuildBlock, 0, stream>>>(nodes_full, live, new_index, n_built, nodes);
   e = hipGetLastError();
   if (e != hipSuccess) { (void)hipFree(prims); (void)hipFree(nodes); return std::string("compact_kernel: ") + hipGetErrorString(e); }
-  gather_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_prims_by_id, order, n, prims);
+  gather_kernel<<<blocks_for(un), kBuildBlock, 0, stream>>>(d_prims_by_id, new_order, n, prims);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipEventRecord(ev1, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);

@@ -782,7 +782,7 @@ std::string build_device_tree(hipStream_t stream, const float* d_boxes, const Pr
     uint32_t n_applied = 0;
     LBVH_HIP(hipMemcpyAsync(&n_applied, applied, sizeof n_applied, hipMemcpyDeviceToHost, stream));
     LBVH_HIP(hipStreamSynchronize(stream));
-    if (std::getenv("PTK_LBVH_REPORT")) fprintf(stderr, "[ptk lbvh] rotation pass %d: %u trades\n", pass, n_applied);
+    if (std::getenv("PTK_LBVH_REPORT")) fprintf(stderr, "[ptk lbvh] restructuring pass %d: %u changes\n", pass, n_applied);
     if (n_applied == 0u) break;
     std::string why = relevel();
     if (!why.empty()) return why;

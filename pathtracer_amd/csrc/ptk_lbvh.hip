@@ -341,6 +341,15 @@ __global__ __launch_bounds__(kBuildBlock) void expand_level_kernel(const NodePai
   if (nd.child1 >= 0) list[atomicAdd(counter, 1u)] = (uint32_t)nd.child1;
 }
 
+// How the fitted tree is restructured: treelets (treelet_level_kernel below) or, with 0, rotations alone.
+// Measured (82k / 1.3M triangles): treelets of 6, two passes: box tests per ray 21.5 -> 20.0 and 24.9 -> 23.4, frame rate
+// +2.2 % / +0.8 %, build 8.5 -> 11.9 ms and 11.7 -> 17.7 ms; of 7: +2.3 % / +1.1 % for 17 and 26 ms; of 5: slower
+// frames unless small gains are refused.  0 builds the rotations alone.
+#ifndef PTK_LBVH_TREELET
+#define PTK_LBVH_TREELET 6  // subtrees per treelet
+#endif
+
+#if PTK_LBVH_TREELET < 3
 // Tree rotations, as the host builder does them after its build (ptk_build.cpp): a child of a node trades places with a
 // grandchild on the other side when the inner child left behind gets a smaller box.  One level per launch, deepest
 // first, so that a thread owns its node and that node's two children; `level` is the level of these nodes (root = 1),
@@ -411,17 +420,13 @@ __global__ __launch_bounds__(kBuildBlock) void rotate_level_kernel(NodePair* nod
   subtree[i] = 1u + (link[0] >= 0 ? subtree[link[0]] : 0u) + (link[1] >= 0 ? subtree[link[1]] : 0u);
 }
 
+#endif  // rotations
+
 // Treelet restructuring (after Karras and Aila, "Fast parallel construction of high-quality bounding volume
 // hierarchies"): below every node a treelet of up to K subtrees is opened (always the inner node with the largest
 // box next) and the binary tree over those subtrees with the least inner surface area - found by dynamic programming
 // over their subsets - replaces the one that was there.  A rotation is the case K = 3.  One level per launch, deepest
 // first: a thread owns its node and everything below it.  Trees that would exceed `limit` levels are left alone.
-// Measured (82k / 1.3M triangles): treelets of 6, two passes: box tests per ray 21.5 -> 20.0 and 24.9 -> 23.4, frame rate
-// +2.2 % / +0.8 %, build 8.5 -> 11.9 ms and 11.7 -> 17.7 ms; of 7: +2.3 % / +1.1 % for 17 and 26 ms; of 5: slower
-// frames unless small gains are refused.  0 builds the rotations alone.
-#ifndef PTK_LBVH_TREELET
-#define PTK_LBVH_TREELET 6  // subtrees per treelet
-#endif
 #ifndef PTK_LBVH_TREELET_MIN_GAIN
 #define PTK_LBVH_TREELET_MIN_GAIN 0.0f
 #endif

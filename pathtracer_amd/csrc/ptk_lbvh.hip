@@ -348,6 +348,10 @@ __global__ __launch_bounds__(kBuildBlock) void expand_level_kernel(const NodePai
 #ifndef PTK_LBVH_TREELET
 #define PTK_LBVH_TREELET 6  // subtrees per treelet
 #endif
+#ifndef PTK_LBVH_ROTATION_PASSES
+#define PTK_LBVH_ROTATION_PASSES 2
+#endif
+constexpr int kRotationPasses = PTK_LBVH_ROTATION_PASSES;  // passes of either kind
 
 #if PTK_LBVH_TREELET < 3
 // Tree rotations, as the host builder does them after its build (ptk_build.cpp): a child of a node trades places with a
@@ -355,10 +359,6 @@ __global__ __launch_bounds__(kBuildBlock) void expand_level_kernel(const NodePai
 // first, so that a thread owns its node and that node's two children; `level` is the level of these nodes (root = 1),
 // a trade pushes one subtree a level down and is only made where the tree stays within `limit` levels of inner nodes.
 // height[i]: levels of inner nodes from i down.
-#ifndef PTK_LBVH_ROTATION_PASSES
-#define PTK_LBVH_ROTATION_PASSES 2
-#endif
-constexpr int kRotationPasses = PTK_LBVH_ROTATION_PASSES;
 // A trade has to shrink the inner child's area by this part of it.  Measured on these trees: the few trades with large
 // gains are worth +1.7 % (82k triangles) and +2.8 % (1.3M triangles) of the frame rate, taking every trade with any
 // gain (tens of thousands more) loses 2 % again.
